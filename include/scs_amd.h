@@ -1,0 +1,258 @@
+/*
+ * scs_amd.h -- C ABI of the MI355X-native ADMM hot path for SCS.
+ *
+ * One shared library (scs_amd/lib/libscsamd.so, fp64; libscsamd_f32.so when
+ * built with -DSFLOAT) exports three concentric boundaries.  Every entry point
+ * below is bound exactly as the reference (cvxgrp/scs v3.2.11) binds the one it
+ * replaces; citations are <file>:<line> relative to the reference tree.
+ *
+ *   B2  whole-solve API             reference include/scs.h:271-338
+ *         scs_init  scs_update  scs_solve  scs_finish  scs
+ *         scs_set_default_settings  scs_version
+ *       The iterate vectors live in HBM for the whole scs_solve; the host only
+ *       sees scalars (residual norms, tau, CG counts) and, every
+ *       acceleration_interval iterations, the vector v for Anderson
+ *       acceleration (host side by design).
+ *
+ *   B1  linear-system plugin        reference include/linsys.h:25-71
+ *         scs_init_lin_sys_work  scs_solve_lin_sys  scs_update_lin_sys_diag_r
+ *         scs_free_lin_sys_work  scs_get_lin_sys_method
+ *       Host pointers in/out, identical contract to linsys/cpu/indirect
+ *       (private.c:221-349): `b` is overwritten by [x; y], `s` may be NULL,
+ *       0 == success, NULL on init failure.  These five symbols are also
+ *       exported by scs_amd/lib/libscsamd_linsys.so (nothing else in it), which
+ *       is what a reference build links instead of linsys/<backend>/private.o.
+ *
+ *   B1' cone projection             reference include/cones.h:80-90
+ *         scs_amd_cone_init  scs_amd_cone_proj_dual  scs_amd_cone_finish
+ *       (the reference has no plugin API for cones; INTEGRATION.md shows the
+ *       three-line shim that maps _scs_proj_dual_cone onto these).
+ *
+ * Plain C types only: pointers, sizes, the structs below.  No HIP or torch type
+ * crosses this boundary.  Struct layouts are ABI facts of the reference and are
+ * restated field-for-field (include/scs.h:47-244, include/aa_stats.h:21-42,
+ * include/scs_types.h:13-32); scs_int is 32-bit (DLONG builds are not
+ * supported by this backend and scs_init refuses nothing silently: the header
+ * simply does not offer the 64-bit typedef).
+ */
+#ifndef SCS_AMD_H
+#define SCS_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- primitive types (reference include/scs_types.h:13-32) ------------- */
+typedef int scs_int;
+#ifndef SFLOAT
+typedef double scs_float;
+#else
+typedef float scs_float;
+#endif
+
+/* ---- exit flags (reference include/scs.h:33-42) ------------------------ */
+#define SCS_INFEASIBLE_INACCURATE (-7)
+#define SCS_UNBOUNDED_INACCURATE (-6)
+#define SCS_SIGINT (-5)
+#define SCS_FAILED (-4)
+#define SCS_INDETERMINATE (-3)
+#define SCS_INFEASIBLE (-2)
+#define SCS_UNBOUNDED (-1)
+#define SCS_UNFINISHED (0)
+#define SCS_SOLVED (1)
+#define SCS_SOLVED_INACCURATE (2)
+
+/* ---- opaque workspaces -------------------------------------------------- */
+typedef struct SCS_WORK ScsWork;                /* B2 */
+typedef struct SCS_LIN_SYS_WORK ScsLinSysWork;  /* B1 */
+typedef struct SCS_AMD_CONE_WORK ScsAmdConeWork; /* B1' */
+
+/* ---- data structs ------------------------------------------------------- */
+/* CSC, zero based (reference include/scs.h:47-58). */
+typedef struct {
+  scs_float *x; /* values, nnz                */
+  scs_int *i;   /* row indices, nnz           */
+  scs_int *p;   /* column pointers, n + 1     */
+  scs_int m;    /* rows                       */
+  scs_int n;    /* columns                    */
+} ScsMatrix;
+
+/* reference include/scs.h:61-101 */
+typedef struct {
+  scs_int normalize;
+  scs_float scale;
+  scs_int adaptive_scale;
+  scs_float rho_x;
+  scs_int max_iters;
+  scs_float eps_abs;
+  scs_float eps_rel;
+  scs_float eps_infeas;
+  scs_float alpha;
+  scs_float time_limit_secs;
+  scs_int verbose;
+  scs_int warm_start;
+  scs_int acceleration_lookback;
+  scs_int acceleration_interval;
+  scs_int acceleration_type_1;
+  scs_float acceleration_regularization;
+  scs_float acceleration_relaxation;
+  const char *write_data_filename;
+  const char *log_csv_filename;
+} ScsSettings;
+
+/* reference include/scs.h:104-119 */
+typedef struct {
+  scs_int m;
+  scs_int n;
+  ScsMatrix *A; /* m x n                               */
+  ScsMatrix *P; /* n x n upper triangle, or NULL       */
+  scs_float *b; /* m                                   */
+  scs_float *c; /* n                                   */
+} ScsData;
+
+/* reference include/scs.h:122-172 (spectral-cone members are compiled out of
+ * the default reference build, scs.mk:195, and are not part of this ABI). */
+typedef struct {
+  scs_int z;      /* zero cone rows                                  */
+  scs_int l;      /* nonnegative orthant rows                        */
+  scs_float *bu;  /* box upper bounds, bsize - 1                     */
+  scs_float *bl;  /* box lower bounds, bsize - 1                     */
+  scs_int bsize;  /* box cone length including t                     */
+  scs_int *q;     /* second-order cone sizes                         */
+  scs_int qsize;
+  scs_int *s;     /* PSD cone matrix dimensions                      */
+  scs_int ssize;
+  scs_int *cs;    /* complex PSD (host fallback absent: rejected)    */
+  scs_int cssize;
+  scs_int ep;     /* exponential cones (rejected by this backend)    */
+  scs_int ed;
+  scs_float *p;   /* power cone parameters (rejected by this backend) */
+  scs_int psize;
+} ScsCone;
+
+/* reference include/scs.h:180-187 */
+typedef struct {
+  scs_float *x;
+  scs_float *y;
+  scs_float *s;
+} ScsSolution;
+
+/* reference include/aa_stats.h:21-42 */
+typedef struct {
+  scs_int iter;
+  scs_int n_accept;
+  scs_int n_reject_lapack;
+  scs_int n_reject_rank0;
+  scs_int n_reject_nonfinite;
+  scs_int n_reject_weight_cap;
+  scs_int n_safeguard_reject;
+  scs_int last_rank;
+  scs_float last_aa_norm;
+  scs_float last_regularization;
+} AaStats;
+
+/* reference include/scs.h:190-244 */
+typedef struct {
+  scs_int iter;
+  char status[128];
+  char lin_sys_solver[128];
+  scs_int status_val;
+  scs_int scale_updates;
+  scs_float pobj;
+  scs_float dobj;
+  scs_float res_pri;
+  scs_float res_dual;
+  scs_float gap;
+  scs_float res_infeas;
+  scs_float res_unbdd_a;
+  scs_float res_unbdd_p;
+  scs_float setup_time; /* ms */
+  scs_float solve_time; /* ms */
+  scs_float scale;
+  scs_float comp_slack;
+  scs_int rejected_accel_steps;
+  scs_int accepted_accel_steps;
+  AaStats aa_stats;
+  scs_float lin_sys_time; /* ms */
+  scs_float cone_time;    /* ms */
+  scs_float accel_time;   /* ms */
+} ScsInfo;
+
+/* ======================= B2: whole-solve API ============================== */
+/* replaces src/scs.c:1245 (scs_init)   -- validates, deep-copies, equilibrates
+ * on the host, then uploads A (both orientations), b, c, D, E once. */
+ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs);
+/* replaces src/scs.c:1287 */
+scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c);
+/* replaces src/scs.c:1327 -- the device-resident ADMM loop */
+scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info,
+                  scs_int warm_start);
+/* replaces src/scs.c:1486 */
+void scs_finish(ScsWork *w);
+/* replaces src/scs.c:1538 */
+scs_int scs(const ScsData *d, const ScsCone *k, const ScsSettings *stgs,
+            ScsSolution *sol, ScsInfo *info);
+/* replaces src/util.c:158 */
+void scs_set_default_settings(ScsSettings *stgs);
+/* replaces src/scs_version.c */
+const char *scs_version(void);
+
+/* ======================= B1: linear-system plugin ========================= */
+/* replaces linsys/cpu/indirect/private.c:225 (callers src/scs.c:1092) */
+ScsLinSysWork *scs_init_lin_sys_work(const ScsMatrix *A, const ScsMatrix *P,
+                                     const scs_float *diag_r);
+/* replaces private.c:284 (callers src/scs.c:763,1127) */
+scs_int scs_solve_lin_sys(ScsLinSysWork *w, scs_float *b, const scs_float *s,
+                          scs_float tol);
+/* replaces private.c:327 (caller src/scs.c:1220) */
+scs_int scs_update_lin_sys_diag_r(ScsLinSysWork *w,
+                                  const scs_float *new_diag_r);
+/* replaces private.c:333 (caller src/scs.c:1493) */
+void scs_free_lin_sys_work(ScsLinSysWork *w);
+/* replaces private.c:221 (callers src/scs.c:127,1346) */
+const char *scs_get_lin_sys_method(void);
+
+/* ======================= B1': cone projection ============================= */
+/* replaces src/cones.c:1498 (_scs_init_cone).  `k` is read, never mutated: the
+ * box bounds are copied and the lazy D-normalisation of cones.c:1161-1177 is
+ * applied to the copy when D != NULL.  D may be NULL (un-normalised cones). */
+ScsAmdConeWork *scs_amd_cone_init(const ScsCone *k, scs_int m,
+                                  const scs_float *D);
+/* replaces src/cones.c:1552 (_scs_proj_dual_cone): x (host, length m) is
+ * overwritten by its projection onto the DUAL cone under the r_y metric;
+ * r_y may be NULL (Euclidean).  Returns <0 on failure, like the reference. */
+scs_int scs_amd_cone_proj_dual(ScsAmdConeWork *c, scs_float *x,
+                               const scs_float *r_y);
+/* replaces src/cones.c:338 (_scs_finish_cone) */
+void scs_amd_cone_finish(ScsAmdConeWork *c);
+
+/* ======================= instrumentation ================================== */
+/* Not in the reference (its `tot_cg_its`, private.h:28, is never surfaced).
+ * Counters accumulate per workspace since init / since the last reset.  Kernel
+ * times come from HIP events recorded on the library's own stream. */
+typedef struct {
+  long long cg_iters;        /* PCG iterations, all solves                   */
+  long long lin_sys_solves;  /* scs_solve_lin_sys calls                      */
+  long long mat_vecs;        /* applications of R_x + P + A' R_y^-1 A        */
+  long long spmv_launches;   /* CSR SpMV kernel launches (both orientations) */
+  double spmv_ms;            /* summed HIP-event time of those launches      */
+  double cg_ms;              /* summed HIP-event time of whole PCG solves    */
+  double cone_ms;            /* summed HIP-event time of cone projections    */
+  long long cone_projs;
+  long long nnz;             /* nnz(A)                                       */
+  long long spmv_bytes;      /* algorithmic bytes of ONE mat_vec (2 SpMV)    */
+} ScsAmdStats;
+
+void scs_amd_linsys_get_stats(const ScsLinSysWork *w, ScsAmdStats *out);
+void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on);
+void scs_amd_get_stats(const ScsWork *w, ScsAmdStats *out);
+void scs_amd_set_profiling(ScsWork *w, scs_int on);
+/* number of visible HIP devices, or <0 with no usable runtime (never throws) */
+scs_int scs_amd_device_count(void);
+/* select the device used by subsequently created workspaces (default 0) */
+scs_int scs_amd_set_device(scs_int dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCS_AMD_H */

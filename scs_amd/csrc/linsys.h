@@ -1,0 +1,83 @@
+// linsys.h -- device-resident Jacobi-PCG on the reduced KKT system
+//     (R_x + P + A' R_y^{-1} A) x = r_x + A' R_y^{-1} r_y ,  y = R_y^{-1}(A x - r_y)
+// i.e. the algorithm of reference linsys/cpu/indirect/private.c:133-324, with
+// every vector in HBM and the loop controlled from the device.
+#pragma once
+#include "spmv.h"
+
+namespace scsamd {
+
+// Control block of one PCG solve, lives in device memory; the host reads it back
+// once per enqueued batch of iterations.
+struct CgCtl {
+  real ztr[2];   // z'r, double-buffered by iteration parity
+  real norm_r;   // ||r||_inf after the last completed iteration
+  real tol;      // tolerance of this solve
+  real rhs_norm; // ||b||_inf over n+m on entry
+  int zero_rhs;  // ||b||_inf <= 1e-12: solution is 0, everything else is skipped
+  int cg_done;   // converged (or breakdown): remaining iteration kernels return
+  int iters;     // PCG iterations performed (reference counting, private.c:203,216)
+  int pad;
+};
+
+struct LinSys {
+  int n = 0, m = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool has_P = false;
+
+  CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector
+  CsrDev A;  // CSR(A): m rows, gathers an n-vector
+  CsrDev P;  // full symmetric CSR of P (n x n), optional
+  DevBuf<real> Pdiag; // sum of stored diagonal entries of P per column
+
+  DevBuf<real> rx, ry;               // R_x (n), R_y (m)
+  DevBuf<real> M, p, r, Gp, z, Pp;   // n each
+  DevBuf<real> tmp;                  // m
+  DevBuf<real> partA, partB;         // reduction partials
+  DevBuf<CgCtl> ctl;
+  PinnedBuf<CgCtl> hctl;
+
+  // staging for the host-pointer boundary (B1)
+  DevBuf<real> b_stage, s_stage, dr_stage;
+
+  // statistics / profiling
+  long long tot_cg_its = 0, n_solves = 0, n_matvecs = 0, n_spmv = 0;
+  int last_its = 16;
+  bool profiling = false;
+  EventTimer spmv_timer, cg_timer;
+  long long spmv_sample_ctr = 0;
+
+  LinSys() = default;
+  ~LinSys();
+  LinSys(const LinSys &) = delete;
+
+  // A, P: host CSC as handed over by the reference (normalized data).
+  void init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s);
+  // diag_r = [R_x (n); R_y (m)] : host or device source
+  void set_diag_r_host(const real *diag_r);
+  void set_diag_r_dev(const real *diag_r_dev);
+  // Solve in place on device memory: b = [r_x; r_y] -> [x; y].  s: warm start
+  // (device, length n) or nullptr.  If warm_part != nullptr the tolerance is
+  // formed on the device as
+  //     tol = max(1e-12, 0.2 * min(tol, max(warm_part[0..warm_cnt)) * warm_scale))
+  // (reference src/scs.c:745-762), otherwise `tol` is used as given.
+  // Returns the PCG iteration count (>= 0).
+  int solve_dev(real *b, const real *s, real tol, const real *warm_part = nullptr,
+                int warm_cnt = 0, real warm_scale = 0);
+  // y_out(n) = (R_x + P + A' R_y^-1 A) x  -- exposed for tests / roofline runs
+  void mat_vec_dev(const real *x, real *y_out, real *dot_partials);
+  // plain products for the residual computation (reference src/scs.c:559,581)
+  void mul_A(const real *x_n, real *y_m);  // y = A x
+  void mul_At(const real *y_m, real *x_n); // x = A' y
+  void mul_P(const real *x_n, real *y_n);  // y = P x (full symmetric)
+  long long matvec_bytes() const { return A.algorithmic_bytes() + At.algorithmic_bytes(); }
+  void harvest_timers();
+
+private:
+  void build_preconditioner();
+  void launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, const EpiArgs &e,
+                   const int *skip);
+};
+
+} // namespace scsamd

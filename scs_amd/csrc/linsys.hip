@@ -1,0 +1,552 @@
+// linsys.hip -- Jacobi-preconditioned CG on the reduced KKT system, device
+// resident and device controlled, plus the B1 host-pointer C ABI.
+//
+// What it computes is exactly reference linsys/cpu/indirect/private.c:
+//   scs_solve_lin_sys :284-324   rhs fold-in, pcg, back-substitution for y
+//   pcg               :133-217   stop on ||r||_inf < tol, early-out, breakdown
+//   mat_vec           :106-119   y = R_x x + P x + A' R_y^-1 A x
+//   set_preconditioner:50-82     M = 1 / diag(R_x + P + A' R_y^-1 A)
+// How it runs is MI355X-first: four kernels per CG iteration
+//   K1 csr_stream<DIV>   tmp = R_y^-1 (A p)
+//   K2 csr_stream<GP>    Gp = R_x p + P p + A' tmp,  partials of p'Gp
+//   K3 cg_update         alpha; x += alpha p; r -= alpha Gp; z = M r; partials z'r, |r|_inf
+//   K4 cg_direction      convergence test; beta; p = z + beta p
+// with all scalars (alpha, beta, z'r, ||r||, tol, done) living in HBM.  The host
+// enqueues iterations in batches sized from the previous solve's count and reads
+// one control block per batch; kernels issued past convergence return at once,
+// so the iterate returned is exactly the first one meeting the tolerance.
+#include "linsys.h"
+#include <algorithm>
+
+namespace scsamd {
+
+constexpr int VEC_MAX_GRID = 2048;
+constexpr int PART_CAP = 4096; // >= SPMV_MAX_GRID and >= VEC_MAX_GRID
+
+static inline int vec_grid(long long len) {
+  long long g = (len + SCSAMD_BLOCK - 1) / SCSAMD_BLOCK;
+  if (g < 1) g = 1;
+  if (g > VEC_MAX_GRID) g = VEC_MAX_GRID;
+  return (int)g;
+}
+
+// ----------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_absmax_partial(const real *__restrict__ v, int len,
+                                                                 real *part) {
+  __shared__ real red[4];
+  real mx = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+    real a = absval(v[i]);
+    mx = a > mx ? a : mx;
+  }
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = mx;
+}
+
+// private.c:296-303: zero-rhs short circuit, tmp = R_y^-1 r_y; also arms the
+// control block for this solve (and, optionally, forms the tolerance of
+// src/scs.c:745-762 from the warm-start norm partials).
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_rhs_prep(real *b, const real *__restrict__ ry,
+                                                           real *tmp, int n, int m,
+                                                           const real *part, int pcount, CgCtl *ctl,
+                                                           real tol, const real *warm_part,
+                                                           int warm_cnt, real warm_scale) {
+  __shared__ real red[4];
+  const real nb = reduce_partials_max(part, pcount, red);
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+  const bool zero = nb <= (real)1e-12;
+  if (zero) {
+    for (int i = gtid; i < n + m; i += gs) b[i] = 0;
+  } else {
+    for (int i = gtid; i < m; i += gs) tmp[i] = b[n + i] / ry[i];
+  }
+  real t = tol;
+  if (warm_part) {
+    const real nw = reduce_partials_max(warm_part, warm_cnt, red) * warm_scale;
+    t = t < nw ? t : nw;
+    t = (real)0.2 * t; // CG_TOL_FACTOR, include/glbopts.h:250
+    t = t > (real)1e-12 ? t : (real)1e-12; // CG_BEST_TOL, glbopts.h:247
+  }
+  if (gtid == 0) {
+    ctl->zero_rhs = zero ? 1 : 0;
+    ctl->cg_done = zero ? 1 : 0;
+    ctl->iters = 0;
+    ctl->tol = t;
+    ctl->rhs_norm = nb;
+    ctl->norm_r = 0;
+    ctl->ztr[0] = 0;
+    ctl->ztr[1] = 0;
+  }
+}
+
+// private.c:145-172 (residual, preconditioned residual, z'r, ||r||)
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_init(real *x, const real *__restrict__ s, real *r,
+                                                          real *z, const real *__restrict__ M, int n,
+                                                          real *part_ztr, real *part_max,
+                                                          const CgCtl *ctl) {
+  __shared__ real red[4];
+  if (ctl->zero_rhs) return;
+  real ztr = 0, mx = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    real ri;
+    if (s) {
+      ri = x[i] - r[i]; // r held G s; r = b - G s
+      x[i] = s[i];
+    } else {
+      ri = x[i];
+      x[i] = 0;
+    }
+    r[i] = ri;
+    const real zi = ri * M[i];
+    z[i] = zi;
+    ztr += zi * ri;
+    const real a = absval(ri);
+    mx = a > mx ? a : mx;
+  }
+  ztr = block_sum(ztr, red);
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) {
+    part_ztr[blockIdx.x] = ztr;
+    part_max[blockIdx.x] = mx;
+  }
+}
+
+// private.c:163 early-out with max(tol, 1e-12); p = z
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_start(real *p, const real *__restrict__ z, int n,
+                                                           const real *part_ztr, const real *part_max,
+                                                           int pcount, CgCtl *ctl) {
+  __shared__ real red[4];
+  if (ctl->zero_rhs) return;
+  const real ztr = reduce_partials_sum(part_ztr, pcount, red);
+  const real nr = reduce_partials_max(part_max, pcount, red);
+  const real tol = ctl->tol;
+  const real thr = tol > (real)1e-12 ? tol : (real)1e-12;
+  const bool conv = nr < thr;
+  if (!conv)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = z[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->ztr[0] = ztr;
+    ctl->norm_r = nr;
+    if (conv) ctl->cg_done = 1;
+  }
+}
+
+// private.c:181-197
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, real *z,
+                                                            const real *__restrict__ p,
+                                                            const real *__restrict__ Gp,
+                                                            const real *__restrict__ M, int n,
+                                                            const real *part_pgp, int cnt_pgp,
+                                                            real *part_ztr, real *part_max,
+                                                            const CgCtl *ctl, int parity) {
+  __shared__ real red[4];
+  if (ctl->cg_done) return;
+  const real pgp = reduce_partials_sum(part_pgp, cnt_pgp, red);
+  const real alpha = ctl->ztr[parity] / pgp;
+  real ztr = 0, mx = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const real pi = p[i], gi = Gp[i];
+    x[i] += alpha * pi;
+    const real ri = r[i] + (-alpha) * gi;
+    r[i] = ri;
+    const real zi = ri * M[i];
+    z[i] = zi;
+    ztr += zi * ri;
+    const real a = absval(ri);
+    mx = a > mx ? a : mx;
+  }
+  ztr = block_sum(ztr, red);
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) {
+    part_ztr[blockIdx.x] = ztr;
+    part_max[blockIdx.x] = mx;
+  }
+}
+
+// private.c:202-214
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const real *__restrict__ z, int n,
+                                                               const real *part_ztr,
+                                                               const real *part_max, int pcount,
+                                                               CgCtl *ctl, int parity) {
+  __shared__ real red[4];
+  if (ctl->cg_done) return;
+  const real ztr = reduce_partials_sum(part_ztr, pcount, red);
+  const real nr = reduce_partials_max(part_max, pcount, red);
+  const real ztr_prev = ctl->ztr[parity];
+  const bool conv = nr < ctl->tol;
+  const bool brk = !conv && ztr_prev == (real)0;
+  if (!conv && !brk) {
+    const real beta = ztr / ztr_prev;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+      p[i] = z[i] + beta * p[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->ztr[parity ^ 1] = ztr;
+    ctl->norm_r = nr;
+    if (!brk) ctl->iters += 1; // converged at i -> i+1 ; breakdown returns i (private.c:203,216)
+    if (conv || brk) ctl->cg_done = 1;
+  }
+}
+
+// private.c:50-82, one lane per column of A (= row of CSR(A'))
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_precond(CsrView At, const real *__restrict__ rx,
+                                                          const real *__restrict__ ry,
+                                                          const real *__restrict__ pdiag, real *M) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < At.rows; i += gridDim.x * blockDim.x) {
+    real acc = rx[i];
+    for (int k = At.ptr[i]; k < At.ptr[i + 1]; ++k) {
+      const real a = At.val[k];
+      acc += a * a / ry[At.idx[k]];
+    }
+    if (pdiag) acc += pdiag[i];
+    M[i] = (real)1 / acc;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------
+LinSys::~LinSys() {
+  if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, const EpiArgs &e,
+                         const int *skip) {
+  const int g = mat.grid();
+  int slot = -1;
+  const bool sample = profiling && ((spmv_sample_ctr++ & 7) == 0);
+  if (sample) slot = spmv_timer.start(stream);
+  CsrView v = mat.view();
+  switch (epi) {
+  case EPI_PLAIN: hipLaunchKernelGGL(csr_stream_kernel<EPI_PLAIN>, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, v, x, y, e, skip); break;
+  case EPI_DIV: hipLaunchKernelGGL(csr_stream_kernel<EPI_DIV>, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, v, x, y, e, skip); break;
+  case EPI_GP: hipLaunchKernelGGL(csr_stream_kernel<EPI_GP>, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, v, x, y, e, skip); break;
+  case EPI_ACC: hipLaunchKernelGGL(csr_stream_kernel<EPI_ACC>, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, v, x, y, e, skip); break;
+  case EPI_NEGDIV: hipLaunchKernelGGL(csr_stream_kernel<EPI_NEGDIV>, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, v, x, y, e, skip); break;
+  default: throw HipError("scs_amd: bad spmv epilogue");
+  }
+  if (sample) spmv_timer.stop(slot, stream);
+  n_spmv++;
+}
+
+// counting-sort transpose CSC(A) -> CSR(A) on the host (what private.c:7-46
+// does); columns within each output row come out sorted.
+static void host_transpose(int rows_out, int cols_out, const int *Ap, const int *Ai, const real *Ax,
+                           std::vector<int> &Cp, std::vector<int> &Ci, std::vector<real> &Cx) {
+  // input: CSC with cols_out columns, rows_out rows.  output: CSR with rows_out rows.
+  const long long nnz = Ap[cols_out];
+  Cp.assign((size_t)rows_out + 1, 0);
+  Ci.resize((size_t)nnz);
+  Cx.resize((size_t)nnz);
+  for (long long k = 0; k < nnz; ++k) Cp[(size_t)Ai[k] + 1]++;
+  for (int i = 0; i < rows_out; ++i) Cp[i + 1] += Cp[i];
+  std::vector<int> nxt(Cp.begin(), Cp.end() - 1);
+  for (int j = 0; j < cols_out; ++j)
+    for (int k = Ap[j]; k < Ap[j + 1]; ++k) {
+      const int q = nxt[Ai[k]]++;
+      Ci[q] = j;
+      Cx[q] = Ax[k];
+    }
+}
+
+void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s) {
+  n = A_csc->n;
+  m = A_csc->m;
+  if (s) {
+    stream = s;
+    own_stream = false;
+  } else {
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    own_stream = true;
+  }
+  // CSC(A) is CSR(A'): upload as is
+  At.upload(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+  {
+    std::vector<int> Cp, Ci;
+    std::vector<real> Cx;
+    host_transpose(m, n, A_csc->p, A_csc->i, A_csc->x, Cp, Ci, Cx);
+    A.upload(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
+  }
+  has_P = P_csc != nullptr;
+  if (has_P) {
+    // expand the stored upper triangle to the full symmetric matrix (CSR == CSC)
+    const int *Pp_ = P_csc->p, *Pi = P_csc->i;
+    const real *Px = P_csc->x;
+    std::vector<int> cnt((size_t)n + 1, 0);
+    std::vector<real> pd((size_t)n, 0);
+    for (int j = 0; j < n; ++j)
+      for (int k = Pp_[j]; k < Pp_[j + 1]; ++k) {
+        const int i = Pi[k];
+        cnt[(size_t)j + 1]++;
+        if (i != j) cnt[(size_t)i + 1]++;
+        else pd[j] += Px[k]; // private.c:69-75
+      }
+    for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+    std::vector<int> nxt(cnt.begin(), cnt.end() - 1), Fi((size_t)cnt[n]);
+    std::vector<real> Fx((size_t)cnt[n]);
+    for (int j = 0; j < n; ++j)
+      for (int k = Pp_[j]; k < Pp_[j + 1]; ++k) {
+        const int i = Pi[k];
+        int q = nxt[j]++; // row j, column i
+        Fi[q] = i;
+        Fx[q] = Px[k];
+        if (i != j) {
+          q = nxt[i]++; // row i, column j
+          Fi[q] = j;
+          Fx[q] = Px[k];
+        }
+      }
+    P.upload(n, n, cnt.data(), Fi.data(), Fx.data(), stream);
+    Pdiag.alloc(n);
+    Pdiag.upload(pd.data(), n, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    Pp.alloc(n);
+  }
+  rx.alloc(n);
+  ry.alloc(m);
+  M.alloc(n);
+  p.alloc(n);
+  r.alloc(n);
+  Gp.alloc(n);
+  z.alloc(n);
+  tmp.alloc(m);
+  partA.alloc(PART_CAP);
+  partB.alloc(PART_CAP);
+  ctl.alloc(1);
+  hctl.alloc(1);
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void LinSys::build_preconditioner() {
+  hipLaunchKernelGGL(k_precond, dim3(vec_grid(n)), dim3(SCSAMD_BLOCK), 0, stream, At.view(), rx.p, ry.p,
+                     has_P ? Pdiag.p : (const real *)nullptr, M.p);
+}
+
+void LinSys::set_diag_r_host(const real *diag_r) {
+  if (dr_stage.n < (size_t)(n + m)) dr_stage.alloc((size_t)n + m);
+  dr_stage.upload(diag_r, (size_t)n + m, stream);
+  HIP_CHECK(hipStreamSynchronize(stream)); // caller's buffer may be pageable and reused
+  set_diag_r_dev(dr_stage.p);
+}
+
+void LinSys::set_diag_r_dev(const real *d) {
+  HIP_CHECK(hipMemcpyAsync(rx.p, d, (size_t)n * sizeof(real), hipMemcpyDeviceToDevice, stream));
+  HIP_CHECK(hipMemcpyAsync(ry.p, d + n, (size_t)m * sizeof(real), hipMemcpyDeviceToDevice, stream));
+  build_preconditioner();
+}
+
+void LinSys::mat_vec_dev(const real *x, real *y_out, real *dot_partials) {
+  EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
+  launch_spmv(EPI_DIV, A, x, tmp.p, e1, nullptr);
+  if (has_P) {
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr};
+    launch_spmv(EPI_PLAIN, P, x, Pp.p, ep, nullptr);
+  }
+  EpiArgs e2{rx.p, x, has_P ? Pp.p : nullptr, dot_partials};
+  launch_spmv(EPI_GP, At, tmp.p, y_out, e2, nullptr);
+  n_matvecs++;
+}
+
+void LinSys::mul_A(const real *x_n, real *y_m) {
+  EpiArgs e{nullptr, nullptr, nullptr, nullptr};
+  launch_spmv(EPI_PLAIN, A, x_n, y_m, e, nullptr);
+}
+void LinSys::mul_At(const real *y_m, real *x_n) {
+  EpiArgs e{nullptr, nullptr, nullptr, nullptr};
+  launch_spmv(EPI_PLAIN, At, y_m, x_n, e, nullptr);
+}
+void LinSys::mul_P(const real *x_n, real *y_n) {
+  if (!has_P) {
+    HIP_CHECK(hipMemsetAsync(y_n, 0, (size_t)n * sizeof(real), stream));
+    return;
+  }
+  EpiArgs e{nullptr, nullptr, nullptr, nullptr};
+  launch_spmv(EPI_PLAIN, P, x_n, y_n, e, nullptr);
+}
+
+void LinSys::harvest_timers() {
+  spmv_timer.harvest();
+  cg_timer.harvest();
+}
+
+int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, int warm_cnt,
+                      real warm_scale) {
+  const int gv = vec_grid(n), gnm = vec_grid((long long)n + m);
+  CgCtl *c = ctl.p;
+  int cg_slot = -1;
+  if (profiling) cg_slot = cg_timer.start(stream);
+
+  hipLaunchKernelGGL(k_absmax_partial, dim3(gnm), dim3(SCSAMD_BLOCK), 0, stream, b, n + m, partA.p);
+  hipLaunchKernelGGL(k_rhs_prep, dim3(gnm), dim3(SCSAMD_BLOCK), 0, stream, b, ry.p, tmp.p, n, m, partA.p,
+                     gnm, c, tol, warm_part, warm_cnt, warm_scale);
+  // b_x += A' R_y^-1 r_y   (private.c:305)
+  {
+    EpiArgs e{nullptr, nullptr, nullptr, nullptr};
+    launch_spmv(EPI_ACC, At, tmp.p, b, e, &c->zero_rhs);
+  }
+  if (s) { // r = G s  (private.c:153)
+    EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
+    launch_spmv(EPI_DIV, A, s, tmp.p, e1, &c->zero_rhs);
+    if (has_P) {
+      EpiArgs ep{nullptr, nullptr, nullptr, nullptr};
+      launch_spmv(EPI_PLAIN, P, s, Pp.p, ep, &c->zero_rhs);
+    }
+    EpiArgs e2{rx.p, s, has_P ? Pp.p : nullptr, nullptr};
+    launch_spmv(EPI_GP, At, tmp.p, r.p, e2, &c->zero_rhs);
+    n_matvecs++;
+  }
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, b, s, r.p, z.p, M.p, n, partA.p,
+                     partB.p, c);
+  hipLaunchKernelGGL(k_cg_start, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, partA.p, partB.p, gv, c);
+
+  // ---- iteration batches ---------------------------------------------------
+  const long long max_its = 10LL * n; // private.c:307
+  long long it = 0;
+  int batch = std::max(4, std::min(last_its + 1, 4096));
+  const int gAt = At.grid();
+  // partial arrays: partA <- p'Gp (K2), partB <- z'r and partB+PART_CAP/2 <- |r| (K3)
+  real *part_pgp = partA.p, *part_ztr = partB.p, *part_max = partB.p + PART_CAP / 2;
+  for (;;) {
+    const int nb = (int)std::min<long long>(batch, max_its - it);
+    for (int j = 0; j < nb; ++j) {
+      const int q = (int)((it + j) & 1);
+      EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
+      launch_spmv(EPI_DIV, A, p.p, tmp.p, e1, &c->cg_done);
+      if (has_P) {
+        EpiArgs ep{nullptr, nullptr, nullptr, nullptr};
+        launch_spmv(EPI_PLAIN, P, p.p, Pp.p, ep, &c->cg_done);
+      }
+      EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, part_pgp};
+      launch_spmv(EPI_GP, At, tmp.p, Gp.p, e2, &c->cg_done);
+      hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, b, r.p, z.p, p.p, Gp.p, M.p,
+                         n, part_pgp, gAt, part_ztr, part_max, c, q);
+      hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, part_ztr,
+                         part_max, gv, c, q);
+    }
+    it += nb;
+    HIP_CHECK(hipMemcpyAsync(hctl.p, c, sizeof(CgCtl), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (hctl.p->cg_done || it >= max_its) break;
+    batch = std::max(4, std::min(last_its / 4 + 1, 1024));
+  }
+  const int its = hctl.p->iters;
+  n_matvecs += its;
+  // y = R_y^-1 (A x - r_y)   (private.c:313-317)
+  {
+    EpiArgs e{ry.p, nullptr, nullptr, nullptr};
+    launch_spmv(EPI_NEGDIV, A, b, b + n, e, &c->zero_rhs);
+  }
+  if (profiling) cg_timer.stop(cg_slot, stream);
+  HIP_CHECK(hipGetLastError());
+  last_its = its;
+  tot_cg_its += its;
+  n_solves++;
+  return its;
+}
+
+} // namespace scsamd
+
+// ============================================================================
+// B1: the reference's linear-system plugin ABI (include/linsys.h:25-71)
+// ============================================================================
+using namespace scsamd;
+
+struct SCS_LIN_SYS_WORK {
+  LinSys ls;
+};
+
+static int g_device = 0;
+
+extern "C" {
+
+scs_int scs_amd_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return -1;
+  return c;
+}
+
+scs_int scs_amd_set_device(scs_int dev) {
+  if (hipSetDevice(dev) != hipSuccess) return -1;
+  g_device = dev;
+  return 0;
+}
+
+const char *scs_get_lin_sys_method(void) { return "sparse-indirect-pcg-hip-gfx950"; }
+
+ScsLinSysWork *scs_init_lin_sys_work(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r) {
+  if (!A || !diag_r) return nullptr;
+  ScsLinSysWork *w = nullptr;
+  try {
+    HIP_CHECK(hipSetDevice(g_device));
+    w = new ScsLinSysWork();
+    w->ls.init(A, P, nullptr);
+    w->ls.b_stage.alloc((size_t)A->n + A->m);
+    w->ls.s_stage.alloc((size_t)A->n);
+    w->ls.set_diag_r_host(diag_r);
+    HIP_CHECK(hipStreamSynchronize(w->ls.stream));
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    delete w;
+    return nullptr;
+  }
+  return w;
+}
+
+scs_int scs_solve_lin_sys(ScsLinSysWork *w, scs_float *b, const scs_float *s, scs_float tol) {
+  if (!w || !b) return -1;
+  if (tol <= 0.) {
+    // same diagnostic as private.c:288-292: caller was not built with -DINDIRECT=1
+    printf("Warning: tol = %4f <= 0, likely compiled without setting INDIRECT flag.\n", (double)tol);
+  }
+  try {
+    LinSys &ls = w->ls;
+    const size_t n = ls.n, m = ls.m;
+    ls.b_stage.upload(b, n + m, ls.stream);
+    if (s) ls.s_stage.upload(s, n, ls.stream);
+    ls.solve_dev(ls.b_stage.p, s ? ls.s_stage.p : nullptr, tol);
+    ls.b_stage.download(b, n + m, ls.stream);
+    HIP_CHECK(hipStreamSynchronize(ls.stream));
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
+  return 0;
+}
+
+scs_int scs_update_lin_sys_diag_r(ScsLinSysWork *w, const scs_float *new_diag_r) {
+  if (!w || !new_diag_r) return -1;
+  try {
+    w->ls.set_diag_r_host(new_diag_r);
+    HIP_CHECK(hipStreamSynchronize(w->ls.stream));
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
+  return 0;
+}
+
+void scs_free_lin_sys_work(ScsLinSysWork *w) { delete w; }
+
+void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on) {
+  if (w) w->ls.profiling = on != 0;
+}
+
+void scs_amd_linsys_get_stats(const ScsLinSysWork *w, ScsAmdStats *out) {
+  if (!w || !out) return;
+  LinSys &ls = const_cast<LinSys &>(w->ls);
+  (void)hipStreamSynchronize(ls.stream);
+  ls.harvest_timers();
+  memset(out, 0, sizeof *out);
+  out->cg_iters = ls.tot_cg_its;
+  out->lin_sys_solves = ls.n_solves;
+  out->mat_vecs = ls.n_matvecs;
+  out->spmv_launches = ls.spmv_timer.samples; // launches that were event-timed
+  out->spmv_ms = ls.spmv_timer.total_ms;
+  out->cg_ms = ls.cg_timer.total_ms;
+  out->nnz = ls.A.nnz;
+  out->spmv_bytes = ls.matvec_bytes();
+}
+
+} // extern "C"

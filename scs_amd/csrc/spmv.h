@@ -1,0 +1,188 @@
+// spmv.h -- CSR sparse mat-vec for CDNA4, "stream" formulation.
+//
+// Replaces SCS(accum_by_atrans) (reference linsys/scs_matrix.c:161-186), which
+// is a row-parallel CSR product on the transpose, and the cuSPARSE calls of the
+// reference's CUDA backend (linsys/gpu/gpu.c:14-28).  Both orientations of A
+// are stored as CSR (CSC(A) *is* CSR(A')), so every product here is
+// "y_r (op)= sum_k val[k] * x[idx[k]]" over a row.
+//
+// Why not wave-per-row: rows are short (10 nnz in CSR(A'), Poisson(5) in CSR(A)
+// on the headline config), so a 64-lane wave per row idles >80 % of its lanes
+// and issues 40-byte loads.  Instead a workgroup owns a contiguous run of rows
+// holding <= NNZ_PER_BLOCK entries:
+//   phase 1  all 256 lanes stream val/idx with unit stride (fully coalesced,
+//            8 independent loads in flight per lane), gather x[idx] (served by
+//            L2 / Infinity Cache: x is 8-16 MB), and park the products in LDS;
+//   phase 2  one lane per row walks its products in LDS in index order -- the
+//            same summation order as the reference's scalar loop -- and applies
+//            the fused epilogue.
+// A row longer than NNZ_PER_BLOCK gets a workgroup to itself (tree reduction).
+// The grid is capped and strides over row-blocks so a fused dot product leaves
+// at most SPMV_MAX_GRID partials.
+#pragma once
+#include "common.h"
+
+namespace scsamd {
+
+typedef scs_float real;
+
+constexpr int NNZ_PER_BLOCK = 2048; // products staged in LDS per row-block (16 KB fp64)
+constexpr int ROWS_PER_BLOCK_MAX = 2048;
+constexpr int SPMV_MAX_GRID = 4096;
+constexpr int SPMV_UNROLL = NNZ_PER_BLOCK / SCSAMD_BLOCK; // 8
+
+struct CsrView {
+  int rows, cols, nblk;
+  const int *ptr;    // rows + 1
+  const int *idx;    // nnz
+  const real *val;   // nnz
+  const int *rowblk; // nblk + 1 : first row of each row-block
+};
+
+// Epilogues (what happens to the row sum `acc`):
+enum {
+  EPI_PLAIN = 0,  // y[r] = acc
+  EPI_DIV = 1,    // y[r] = acc / d[r]                      (z = R_y^-1 A p)
+  EPI_GP = 2,     // y[r] = (y0[r] + acc) + d[r] * xin[r];  partial dot xin.y
+  EPI_ACC = 3,    // y[r] = y[r] + acc  (sum starts at y[r], like the reference)
+  EPI_NEGDIV = 4, // y[r] = (-y[r] + acc) / d[r]            (y = R_y^-1 (A x - r_y))
+};
+
+struct EpiArgs {
+  const real *d;   // divisor (R_y) or multiplier (R_x)
+  const real *xin; // EPI_GP: the vector being multiplied (p), length rows
+  const real *y0;  // EPI_GP: optional initial value (P p) or nullptr
+  real *partial;   // EPI_GP: per-workgroup partial of xin . y, or nullptr
+};
+
+#ifdef __HIPCC__
+template <int EPI>
+__device__ __forceinline__ real epi_init(const EpiArgs &e, const real *y, int r) {
+  if (EPI == EPI_GP) return e.y0 ? e.y0[r] : (real)0;
+  if (EPI == EPI_ACC) return y[r];
+  if (EPI == EPI_NEGDIV) return -y[r];
+  return (real)0;
+}
+template <int EPI>
+__device__ __forceinline__ real epi_apply(const EpiArgs &e, real *y, int r, real acc, real &dot) {
+  real out = acc;
+  if (EPI == EPI_DIV || EPI == EPI_NEGDIV) out = acc / e.d[r];
+  if (EPI == EPI_GP) {
+    const real xr = e.xin[r];
+    out = acc + e.d[r] * xr;
+    dot += xr * out;
+  }
+  y[r] = out;
+  return out;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, const real *__restrict__ x,
+                                                                  real *y, EpiArgs e,
+                                                                  const int *skip) {
+  if (skip && *skip) return;
+  __shared__ real prod[NNZ_PER_BLOCK];
+  __shared__ real red[SCSAMD_BLOCK / SCSAMD_WAVE];
+  const int tid = threadIdx.x;
+  real dot = 0;
+  for (int b = blockIdx.x; b < A.nblk; b += gridDim.x) {
+    const int r0 = A.rowblk[b], r1 = A.rowblk[b + 1];
+    const int k0 = A.ptr[r0], k1 = A.ptr[r1];
+    const int cnt = k1 - k0;
+    if (cnt > NNZ_PER_BLOCK) {
+      // one long row: strided partial sums, workgroup tree reduction
+      real acc = 0;
+      for (int k = k0 + tid; k < k1; k += SCSAMD_BLOCK) acc += A.val[k] * x[A.idx[k]];
+      acc = block_sum(acc, red);
+      if (tid == 0) {
+        acc += epi_init<EPI>(e, y, r0);
+        epi_apply<EPI>(e, y, r0, acc, dot);
+      }
+    } else {
+      // phase 1: coalesced stream + gather, products to LDS
+      int ii[SPMV_UNROLL];
+      real vv[SPMV_UNROLL];
+#pragma unroll
+      for (int j = 0; j < SPMV_UNROLL; ++j) {
+        const int k = tid + j * SCSAMD_BLOCK;
+        const bool ok = k < cnt;
+        ii[j] = ok ? A.idx[k0 + k] : 0;
+        vv[j] = ok ? A.val[k0 + k] : (real)0;
+      }
+      real xx[SPMV_UNROLL];
+#pragma unroll
+      for (int j = 0; j < SPMV_UNROLL; ++j) xx[j] = x[ii[j]];
+#pragma unroll
+      for (int j = 0; j < SPMV_UNROLL; ++j) {
+        const int k = tid + j * SCSAMD_BLOCK;
+        if (k < cnt) prod[k] = vv[j] * xx[j];
+      }
+      __syncthreads();
+      // phase 2: one lane per row, sequential (reference order) sum out of LDS
+      for (int r = r0 + tid; r < r1; r += SCSAMD_BLOCK) {
+        const int a = A.ptr[r] - k0, z = A.ptr[r + 1] - k0;
+        real acc = epi_init<EPI>(e, y, r);
+        for (int k = a; k < z; ++k) acc += prod[k];
+        epi_apply<EPI>(e, y, r, acc, dot);
+      }
+      __syncthreads();
+    }
+  }
+  if (EPI == EPI_GP && e.partial) {
+    dot = block_sum(dot, red);
+    if (tid == 0) e.partial[blockIdx.x] = dot;
+  }
+}
+#endif // __HIPCC__
+
+// ---- device-resident CSR with its row-block table ---------------------------
+struct CsrDev {
+  int rows = 0, cols = 0, nblk = 0;
+  long long nnz = 0;
+  DevBuf<int> ptr, idx, rowblk;
+  DevBuf<real> val;
+  CsrView view() const { return CsrView{rows, cols, nblk, ptr.p, idx.p, val.p, rowblk.p}; }
+  int grid() const { return nblk < SPMV_MAX_GRID ? (nblk > 0 ? nblk : 1) : SPMV_MAX_GRID; }
+  // algorithmic bytes of one product with this matrix:
+  // nnz*(sf+si) + (rows+1)*si + cols*sf + rows*sf
+  long long algorithmic_bytes() const {
+    return nnz * (long long)(sizeof(real) + sizeof(int)) + (long long)(rows + 1) * sizeof(int) +
+           (long long)cols * sizeof(real) + (long long)rows * sizeof(real);
+  }
+  // host CSR arrays -> device, plus the row-block table
+  void upload(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval,
+              hipStream_t s) {
+    rows = rows_;
+    cols = cols_;
+    nnz = hptr[rows_];
+    ptr.alloc((size_t)rows + 1);
+    idx.alloc((size_t)nnz);
+    val.alloc((size_t)nnz);
+    ptr.upload(hptr, (size_t)rows + 1, s);
+    if (nnz) {
+      idx.upload(hidx, (size_t)nnz, s);
+      val.upload(hval, (size_t)nnz, s);
+    }
+    std::vector<int> rb;
+    rb.push_back(0);
+    int r = 0;
+    while (r < rows) {
+      int start = r;
+      long long acc = 0;
+      while (r < rows && (r - start) < ROWS_PER_BLOCK_MAX) {
+        long long rn = (long long)hptr[r + 1] - hptr[r];
+        if (acc + rn > NNZ_PER_BLOCK) break;
+        acc += rn;
+        ++r;
+      }
+      if (r == start) ++r; // a single row longer than the LDS tile: own block
+      rb.push_back(r);
+    }
+    nblk = (int)rb.size() - 1;
+    rowblk.alloc(rb.size());
+    rowblk.upload(rb.data(), rb.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s)); // rb is a local
+  }
+};
+
+} // namespace scsamd

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / the driver)")
+
+
+def _have_gpu():
+    try:
+        from scs_amd import capi
+        lib = capi.load("libscsamd_linsys.so")
+        return lib.scs_amd_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def have_gpu():
+    return _have_gpu()

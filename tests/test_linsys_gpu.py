@@ -1,0 +1,106 @@
+"""B1 parity: our HIP scs_solve_lin_sys vs the reference's CPU indirect backend
+(linsys/cpu/indirect/private.c:284-324) through the SAME C ABI on the same inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from scs_amd import capi
+from tests import probgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref():
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    return pyoracle.load_ref()
+
+
+def _solve_with(lib, matA, matP, dr, b, s, tol):
+    T = lib._scs_types
+    w = lib.scs_init_lin_sys_work(C.byref(matA), C.byref(matP) if matP is not None else None,
+                                  dr.ctypes.data_as(T.fp))
+    assert w
+    out = b.copy()
+    rc = lib.scs_solve_lin_sys(w, out.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp) if s is not None else None, tol)
+    assert rc == 0
+    return w, out
+
+
+@pytest.mark.parametrize("n,m,col_nnz,warm,tol", [
+    (50, 150, 4, False, 1e-12),
+    (1000, 3000, 32, False, 1e-12),
+    (1000, 3000, 32, True, 1e-7),
+    (3000, 7001, 9, True, 1e-4),
+    (20000, 50000, 10, False, 1e-9),
+])
+def test_solve_lin_sys_matches_reference(n, m, col_nnz, warm, tol):
+    ref = _ref()
+    amd = capi.load("libscsamd_linsys.so")
+    rng = np.random.default_rng(n + m)
+    A = probgen.random_csc(m, n, col_nnz, seed=7)
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
+    dr = probgen.diag_r(n, m, z=m // 10)
+    b = rng.uniform(-1, 1, n + m)
+    s = rng.uniform(-1, 1, n) * 0.1 if warm else None
+    wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, tol)
+    wa, xa = _solve_with(amd, prob.matA, None, dr, b, s, tol)
+    # both solved the same SPD system to `tol` in the residual inf-norm; at
+    # tol=1e-12 they agree to rounding, otherwise to a small multiple of tol / lambda_min
+    scale = np.abs(xr).max()
+    if tol <= 1e-9:
+        assert np.abs(xa - xr).max() <= 1e-7 * scale
+    # exact check independent of CG path: KKT residual of our answer
+    x, y = xa[:n], xa[n:]
+    Asp = prob.sparse()
+    r1 = dr[:n] * x + Asp.T @ y - b[:n]
+    r2 = Asp @ x - dr[n:] * y - b[n:]
+    # reduced residual G x - rhs
+    red = r1 + Asp.T @ (r2 / dr[n:])
+    assert np.abs(red).max() < max(tol, 1e-12) * 1.01 + 1e-10 * np.abs(b).max()
+    assert np.abs(r2).max() < 1e-9 * max(1.0, np.abs(b).max()) * dr[n:].max()
+    # second solve on the same workspace + diag_r update
+    dr2 = probgen.diag_r(n, m, z=m // 10, scale=2.5)
+    assert amd.scs_update_lin_sys_diag_r(wa, dr2.ctypes.data_as(capi.T64.fp)) == 0
+    assert ref.scs_update_lin_sys_diag_r(wr, dr2.ctypes.data_as(capi.T64.fp)) == 0
+    b2 = rng.uniform(-1, 1, n + m)
+    o1, o2 = b2.copy(), b2.copy()
+    assert amd.scs_solve_lin_sys(wa, o1.ctypes.data_as(capi.T64.fp), None, 1e-12) == 0
+    assert ref.scs_solve_lin_sys(wr, o2.ctypes.data_as(capi.T64.fp), None, 1e-12) == 0
+    assert np.abs(o1 - o2).max() <= 1e-7 * np.abs(o2).max()
+    amd.scs_free_lin_sys_work(wa)
+    ref.scs_free_lin_sys_work(wr)
+
+
+def test_zero_rhs_short_circuit():
+    amd = capi.load("libscsamd_linsys.so")
+    n, m = 40, 100
+    A = probgen.random_csc(m, n, 3, seed=1)
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
+    dr = probgen.diag_r(n, m, z=10)
+    b = np.full(n + m, 1e-13)
+    w, out = _solve_with(amd, prob.matA, None, dr, b, None, 1e-9)
+    assert np.all(out == 0.0)  # private.c:296-299
+    amd.scs_free_lin_sys_work(w)
+
+
+def test_with_P_matches_reference():
+    ref = _ref()
+    amd = capi.load("libscsamd_linsys.so")
+    import scipy.sparse as sp
+    n, m = 300, 500
+    rng = np.random.default_rng(3)
+    A = probgen.random_csc(m, n, 5, seed=11)
+    B = sp.random(n, n, density=0.02, random_state=5, format="csc")
+    P = (B @ B.T + sp.identity(n) * 0.1).tocsc()
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m), P=P)
+    dr = probgen.diag_r(n, m, z=50)
+    b = rng.uniform(-1, 1, n + m)
+    s = rng.uniform(-1, 1, n)
+    wr, xr = _solve_with(ref, prob.matA, prob.matP, dr, b, s, 1e-12)
+    wa, xa = _solve_with(amd, prob.matA, prob.matP, dr, b, s, 1e-12)
+    assert np.abs(xa - xr).max() <= 1e-8 * np.abs(xr).max()
+    amd.scs_free_lin_sys_work(wa)
+    ref.scs_free_lin_sys_work(wr)
