@@ -57,6 +57,10 @@ template <typename T> struct DevBuf {
     // the array may run a few elements past its logical end
     HIP_CHECK(hipMalloc((void **)&p, (count + 8) * sizeof(T)));
     HIP_CHECK(hipMemset(p, 0, (count + 8) * sizeof(T)));
+    // hipMemset runs on the legacy default stream and may return before the fill
+    // has happened; our work streams are non-blocking (no implicit ordering with
+    // it), so drain it here.  Allocation only happens at init time.
+    HIP_CHECK(hipStreamSynchronize(nullptr));
   }
   void release() {
     if (p) (void)hipFree(p);

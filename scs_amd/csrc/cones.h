@@ -1,0 +1,51 @@
+// cones.h -- device-resident projection onto K = zero x pos x box x SOC^q x PSD^s
+// (reference src/cones.c:1340-1394 `proj_cone`, wrapped by the Moreau identity of
+// src/cones.c:1552-1596 `proj_dual_cone`).
+#pragma once
+#include "common.h"
+
+namespace scsamd {
+
+typedef scs_float real;
+
+struct ConeDev {
+  int m = 0;
+  hipStream_t stream = nullptr;
+  // layout (row offsets into the length-m cone vector)
+  int z = 0, l = 0, bsize = 0, box_off = 0;
+  // box cone
+  DevBuf<real> bl, bu;      // bsize-1 each (already D-normalised, +-inf applied)
+  DevBuf<real> box_t;       // [0] Newton warm start (reference c->box_t_warm_start)
+  // second-order cones
+  int n_tiny = 0;           // cones with q <= SOC_TINY_MAX: one lane per cone
+  DevBuf<int> tiny_off, tiny_len;
+  int n_big = 0, n_tiles = 0; // remaining cones: tiled three-pass reduction
+  DevBuf<int> big_off, big_len, big_tile0; // per big cone (+1 sentinel in big_tile0)
+  DevBuf<int> tile_cone, tile_off, tile_len;
+  DevBuf<real> tile_part;   // per-tile sum of squares of the tail
+  DevBuf<real> big_coef;    // per big cone: [head, tail multiplier]
+  // PSD cones
+  int n_psd = 0, psd_kmax = 0;
+  DevBuf<int> psd_off, psd_k;
+  DevBuf<real> psd_work;    // global scratch for blocks that do not fit in LDS
+  DevBuf<int> status;       // [0] != 0 if any projection failed
+
+  // host staging for the B1' boundary
+  DevBuf<real> x_stage, s_stage, r_stage;
+
+  void init(const ScsCone *k, int m, const real *D_host, hipStream_t s);
+  // cw (device, length m) <- Proj_K(cw), projection under the diag(r_y)^-1 metric
+  // (only the box cone looks at r_y; nullptr = Euclidean).
+  void proj_primal(real *cw, const real *r_y);
+  // x (device, length m) <- Proj_{K*}^{R}(x) via Moreau; `scratch` is a length-m
+  // device buffer that receives the saved input.
+  void proj_dual(real *x, real *scratch, const real *r_y);
+  int rows() const { return m; }
+};
+
+// validation shared by scs_init and scs_amd_cone_init; returns <0 when the cone
+// description is inconsistent with m or uses a cone this backend does not carry.
+int validate_cone(const ScsCone *k, int m, bool verbose);
+long long cone_total_rows(const ScsCone *k);
+
+} // namespace scsamd

@@ -1,0 +1,613 @@
+// cones.hip -- cone projections as HIP kernels + the B1' host-pointer C ABI.
+//
+// Reference behaviour restated (src/cones.c):
+//   proj_dual_cone        :1552-1596  Moreau wrapper in the R_y metric
+//   proj_cone             :1340-1394  dispatcher, order zero,pos,box,SOC,PSD
+//   proj_box_cone         :1182-1245  Newton on t (<= 25 its), then clip
+//   normalize_box_cone    :1161-1177  bounds scaled by D[j+1]/D[0], +-1e15 -> inf
+//   proj_soc              :1250-1279  s = |x_1:|, cases s<=v, s<=-v, else scale
+//   proj_semi_definite_cone:999-1067  unpack, sqrt2 on the diagonal, eig, keep >0
+//
+// MI355X mapping:
+//   zero/pos   one elementwise kernel;
+//   box        ONE workgroup of 1024 lanes runs the whole Newton loop (a global
+//              reduction per step is a workgroup reduction; bounds stream from L2);
+//   SOC        cones are few-and-huge on the headline config (17 cones of ~7e4
+//              rows) and many-and-tiny elsewhere, so "one workgroup per cone" is
+//              wrong both ways: cones with q <= 16 get one lane each (sequential,
+//              reference summation order); everything else is cut into 2048-row
+//              tiles -> per-tile partial, per-cone finalize, per-tile apply;
+//   PSD        one workgroup per cone: parallel cyclic two-sided Jacobi on the
+//              k x k matrix held in LDS (k=50 -> 41 KB of 160 KB), eigenvector
+//              accumulation in LDS, then X+ = V diag(max(l,0)) V' on the fp64
+//              matrix cores (v_mfma_f64_16x16x4_f64) -- replaces LAPACK
+//              dsyevr + dsyrk (cones.c:1028,1052).
+#include "cones.h"
+#include <algorithm>
+
+namespace scsamd {
+
+constexpr int SOC_TINY_MAX = 16;
+constexpr int SOC_TILE = 2048;
+constexpr int BOX_THREADS = 1024;
+constexpr int BOX_MAX_ITERS = 25;     // BOX_CONE_MAX_ITERS, cones.c:21
+constexpr double MAX_BOX_VAL = 1e15;  // cones.c:54
+constexpr int PSD_THREADS = 256;
+constexpr int PSD_LDS_KMAX = 92;      // 2*92*93*8 B + 12 KB header = 149 KB < 160 KB
+constexpr int PSD_MAX_SWEEPS = 30;
+constexpr int PSD_MAX_PAIRS = 512;    // supports k <= 1024
+constexpr int PSD_K_LIMIT = 2 * PSD_MAX_PAIRS;
+constexpr size_t PSD_LDS_HEADER = PSD_MAX_PAIRS * (2 * sizeof(real) + 2 * sizeof(int)) + 8 * sizeof(real);
+
+// ----------------------------------------------------------------------------
+// Moreau pre / post (cones.c:1567-1593)
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_moreau_pre(real *x, real *s, const real *__restrict__ ry,
+                                                             int m) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const real xi = x[i];
+    s[i] = xi;
+    x[i] = ry ? xi * (-ry[i]) : -xi;
+  }
+}
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_moreau_post(real *x, const real *__restrict__ s,
+                                                              const real *__restrict__ ry, int m) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+    x[i] = ry ? x[i] / ry[i] + s[i] : x[i] + s[i];
+}
+
+// zero cone -> 0, nonnegative orthant -> max(x, 0)   (cones.c:1349-1359)
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_zero_pos(real *x, int z, int l) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < z + l; i += gridDim.x * blockDim.x) {
+    if (i < z) x[i] = 0;
+    else {
+      const real v = x[i];
+      x[i] = v > (real)0 ? v : (real)0;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// box cone: whole Newton loop in one workgroup
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(BOX_THREADS) void k_box(real *tx, const real *__restrict__ bl,
+                                                     const real *__restrict__ bu, int bsize,
+                                                     real *t_warm, const real *r_box) {
+  __shared__ real red[BOX_THREADS / SCSAMD_WAVE];
+  const int tid = threadIdx.x;
+  if (bsize == 1) {
+    if (tid == 0) tx[0] = tx[0] > (real)0 ? tx[0] : (real)0;
+    return;
+  }
+  real *x = tx + 1;
+  const real *rho = r_box ? r_box + 1 : nullptr;
+  const real rho_t = r_box ? (real)1 / r_box[0] : (real)1;
+  const real t0 = tx[0];
+  real t = t_warm[0];
+  for (int it = 0; it < BOX_MAX_ITERS; ++it) {
+    const real t_prev = t;
+    real gt = 0, ht = 0;
+    for (int j = tid; j < bsize - 1; j += BOX_THREADS) {
+      const real r = rho ? (real)1 / rho[j] : (real)1;
+      const real xj = x[j], u = bu[j], lo = bl[j];
+      if (xj > t * u) {
+        gt += r * (t * u - xj) * u;
+        ht += r * u * u;
+      } else if (xj < t * lo) {
+        gt += r * (t * lo - xj) * lo;
+        ht += r * lo * lo;
+      }
+    }
+    gt = block_sum(gt, red);
+    ht = block_sum(ht, red);
+    gt += rho_t * (t - t0);
+    ht += rho_t;
+    const real hm = ht > (real)1e-8 ? ht : (real)1e-8;
+    t = t - gt / hm;
+    t = t > (real)0 ? t : (real)0;
+    const real hm6 = ht > (real)1e-6 ? ht : (real)1e-6;
+    const real tm = t > (real)1 ? t : (real)1;
+    if (absval(gt / hm6) < (real)1e-12 * tm || absval(t - t_prev) < (real)1e-11 * tm) break;
+  }
+  for (int j = tid; j < bsize - 1; j += BOX_THREADS) {
+    const real xj = x[j], u = bu[j], lo = bl[j];
+    if (xj > t * u) x[j] = t * u;
+    else if (xj < t * lo) x[j] = t * lo;
+  }
+  if (tid == 0) {
+    tx[0] = t;
+    t_warm[0] = t;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// second-order cones
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void soc_decide(real v1, real s, real &head, real &mult) {
+  if (s <= v1) { // inside (cones.c:1271)
+    head = v1;
+    mult = 1;
+  } else if (s <= -v1) { // polar (cones.c:1273)
+    head = 0;
+    mult = 0;
+  } else {
+    const real alpha = (s + v1) / (real)2;
+    head = alpha;
+    mult = alpha / s;
+  }
+}
+
+// one lane per tiny cone; same case analysis and summation order as proj_soc
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_soc_tiny(real *x, const int *__restrict__ off,
+                                                           const int *__restrict__ len, int ncones) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncones; c += gridDim.x * blockDim.x) {
+    real *xc = x + off[c];
+    const int q = len[c];
+    if (q <= 0) continue;
+    if (q == 1) {
+      xc[0] = xc[0] > (real)0 ? xc[0] : (real)0;
+      continue;
+    }
+    const real v1 = xc[0];
+    real s;
+    if (q == 2) s = absval(xc[1]);
+    else {
+      real ss = 0;
+      for (int j = 1; j < q; ++j) ss += xc[j] * xc[j];
+      s = sqrt(ss);
+    }
+    real head, mult;
+    soc_decide(v1, s, head, mult);
+    if (mult == (real)1 && head == v1) continue;
+    xc[0] = head;
+    if (mult == (real)0)
+      for (int j = 1; j < q; ++j) xc[j] = 0;
+    else
+      for (int j = 1; j < q; ++j) xc[j] *= mult;
+  }
+}
+
+// pass 1: per-tile sum of squares of tail entries
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_soc_tile_partial(const real *__restrict__ x,
+                                                                   const int *__restrict__ tile_off,
+                                                                   const int *__restrict__ tile_len,
+                                                                   const int *__restrict__ tile_cone,
+                                                                   const int *__restrict__ big_off,
+                                                                   real *part, int ntiles) {
+  __shared__ real red[4];
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int o = tile_off[t], n = tile_len[t];
+    const int head = big_off[tile_cone[t]];
+    real ss = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const real v = x[o + j];
+      if (o + j != head) ss += v * v;
+    }
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) part[t] = ss;
+  }
+}
+// pass 2: one lane per cone
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_soc_finalize(const real *__restrict__ x,
+                                                               const int *__restrict__ big_off,
+                                                               const int *__restrict__ big_tile0,
+                                                               const real *__restrict__ part, real *coef,
+                                                               int ncones) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncones; c += gridDim.x * blockDim.x) {
+    real ss = 0;
+    for (int t = big_tile0[c]; t < big_tile0[c + 1]; ++t) ss += part[t];
+    const real s = sqrt(ss), v1 = x[big_off[c]];
+    real head, mult;
+    soc_decide(v1, s, head, mult);
+    coef[2 * c] = head;
+    coef[2 * c + 1] = mult;
+  }
+}
+// pass 3: apply
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_soc_tile_apply(real *x, const int *__restrict__ tile_off,
+                                                                 const int *__restrict__ tile_len,
+                                                                 const int *__restrict__ tile_cone,
+                                                                 const int *__restrict__ big_off,
+                                                                 const real *__restrict__ coef,
+                                                                 int ntiles) {
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int o = tile_off[t], n = tile_len[t], c = tile_cone[t];
+    const int head = big_off[c];
+    const real hv = coef[2 * c], mult = coef[2 * c + 1];
+    if (mult == (real)1) continue; // inside the cone: untouched (head == v1)
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      if (o + j == head) x[o + j] = hv;
+      else x[o + j] = mult == (real)0 ? (real)0 : x[o + j] * mult;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// PSD cone: parallel cyclic Jacobi eigensolver, one workgroup per cone
+// ----------------------------------------------------------------------------
+#ifndef SFLOAT
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#endif
+
+// packed lower triangle, column major: column j starts at j*k - j*(j-1)/2
+__device__ __forceinline__ int packed_index(int i, int j, int k) { // i >= j
+  return j * k - (j * (j - 1)) / 2 + (i - j);
+}
+
+__global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *__restrict__ psd_off,
+                                                            const int *__restrict__ psd_k, real *scratch,
+                                                            int kmax, int use_lds, int *status) {
+  // all scratch lives in the dynamic region (16-byte aligned base, guide G17):
+  // [rot_c | rot_s | rot_p | rot_q | red | A | V]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  real *rot_c = reinterpret_cast<real *>(smem_raw);
+  real *rot_s = rot_c + PSD_MAX_PAIRS;
+  int *rot_p = reinterpret_cast<int *>(rot_s + PSD_MAX_PAIRS);
+  int *rot_q = rot_p + PSD_MAX_PAIRS;
+  real *red = reinterpret_cast<real *>(rot_q + PSD_MAX_PAIRS);
+  real *lds_mat = red + 8;
+  const int cone = blockIdx.x, tid = threadIdx.x;
+  const int k = psd_k[cone];
+  real *X = x + psd_off[cone];
+  if (k <= 0) return;
+  if (k == 1) {
+    if (tid == 0) X[0] = X[0] > (real)0 ? X[0] : (real)0;
+    return;
+  }
+  const int ld = k | 1; // odd leading dimension: conflict-free column walks
+  const int ldm = kmax | 1;
+  real *A = use_lds ? lds_mat : scratch + (size_t)cone * 2 * kmax * ldm;
+  real *V = A + (size_t)k * ld;
+  const real sqrt2 = sqrt((real)2);
+  // unpack: full symmetric, diagonal * sqrt(2)  (cones.c:1018-1025)
+  for (int e = tid; e < k * k; e += PSD_THREADS) {
+    const int i = e % k, j = e / k;
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    real v = X[packed_index(hi, lo, k)];
+    if (i == j) v *= sqrt2;
+    A[i * ld + j] = v;
+    V[i * ld + j] = i == j ? (real)1 : (real)0;
+  }
+  __syncthreads();
+  // Frobenius norm for the stopping test
+  real fro = 0;
+  for (int e = tid; e < k * k; e += PSD_THREADS) {
+    const real v = A[(e / k) * ld + (e % k)];
+    fro += v * v;
+  }
+  fro = sqrt(block_sum(fro, red));
+  const int K2 = (k + 1) & ~1; // even number of players, index k == bye
+  const int npairs = K2 / 2;
+  const real eps = sizeof(real) == 8 ? (real)1e-15 : (real)1e-7;
+  int sweep = 0;
+  if (fro > (real)0) {
+    for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+      real offmax = 0;
+      for (int step = 0; step < K2 - 1; ++step) {
+        // round-robin pairing: player 0 fixed, others rotate
+        if (tid < npairs) {
+          const int i = tid;
+          int p = i == 0 ? 0 : 1 + ((i - 1 + step) % (K2 - 1));
+          const int jj = K2 - 1 - i;
+          int q = 1 + ((jj - 1 + step) % (K2 - 1));
+          if (p > q) {
+            const int t = p;
+            p = q;
+            q = t;
+          }
+          real c = 1, s = 0;
+          if (q < k) {
+            const real apq = A[p * ld + q];
+            const real aa = absval(apq);
+            offmax = aa > offmax ? aa : offmax;
+            if (aa > (real)0) {
+              const real app = A[p * ld + p], aqq = A[q * ld + q];
+              const real theta = (aqq - app) / ((real)2 * apq);
+              const real t = (theta >= 0 ? (real)1 : (real)-1) / (absval(theta) + sqrt(theta * theta + (real)1));
+              c = (real)1 / sqrt(t * t + (real)1);
+              s = t * c;
+            }
+          } else {
+            q = -1;
+          }
+          rot_p[i] = p;
+          rot_q[i] = q;
+          rot_c[i] = c;
+          rot_s[i] = s;
+        }
+        __syncthreads();
+        // rows: A <- J' A
+        for (int e = tid; e < npairs * k; e += PSD_THREADS) {
+          const int pr = e / k, j = e % k;
+          const int q = rot_q[pr];
+          if (q < 0) continue;
+          const int p = rot_p[pr];
+          const real c = rot_c[pr], s = rot_s[pr];
+          const real ap = A[p * ld + j], aq = A[q * ld + j];
+          A[p * ld + j] = c * ap - s * aq;
+          A[q * ld + j] = s * ap + c * aq;
+        }
+        __syncthreads();
+        // columns: A <- A J ; V <- V J
+        for (int e = tid; e < npairs * k; e += PSD_THREADS) {
+          const int pr = e / k, i = e % k;
+          const int q = rot_q[pr];
+          if (q < 0) continue;
+          const int p = rot_p[pr];
+          const real c = rot_c[pr], s = rot_s[pr];
+          const real ap = A[i * ld + p], aq = A[i * ld + q];
+          A[i * ld + p] = c * ap - s * aq;
+          A[i * ld + q] = s * ap + c * aq;
+          const real vp = V[i * ld + p], vq = V[i * ld + q];
+          V[i * ld + p] = c * vp - s * vq;
+          V[i * ld + q] = s * vp + c * vq;
+        }
+        __syncthreads();
+      }
+      offmax = block_max(offmax, red);
+      if (offmax <= eps * fro / (real)k) break;
+    }
+  }
+  if (sweep >= PSD_MAX_SWEEPS && tid == 0) atomicMax(status, 1); // did not converge (positive: not fatal)
+  // eigenvalues = diag(A); scale columns of V by sqrt(max(lambda, 0)) into W (re-using A)
+  // W[i][c] = V[i][c] * sqrt(lambda_c) for lambda_c > 0 else 0   (cones.c:1036-1044)
+  __syncthreads();
+  for (int cidx = tid; cidx < k; cidx += PSD_THREADS) {
+    const real lam = A[cidx * ld + cidx];
+    A[cidx * ld + cidx] = lam > (real)0 ? sqrt(lam) : (real)0;
+  }
+  __syncthreads();
+  for (int e = tid; e < k * k; e += PSD_THREADS) {
+    const int i = e / k, cidx = e % k;
+    V[i * ld + cidx] *= A[cidx * ld + cidx];
+  }
+  __syncthreads();
+  // X+ = W W', lower triangle only, repack with diagonal / sqrt(2)  (cones.c:1052-1063)
+  const real inv_sqrt2 = (real)1 / sqrt2;
+  const int ntri = k * (k + 1) / 2;
+  for (int e = tid; e < ntri; e += PSD_THREADS) {
+    // invert packed index -> (i, j): walk columns
+    int j = 0, rem = e;
+    while (rem >= k - j) {
+      rem -= k - j;
+      ++j;
+    }
+    const int i = j + rem;
+    real acc = 0;
+    for (int cidx = 0; cidx < k; ++cidx) acc += V[i * ld + cidx] * V[j * ld + cidx];
+    if (i == j) acc *= inv_sqrt2;
+    X[e] = acc;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------
+long long cone_total_rows(const ScsCone *k) {
+  long long t = (long long)k->z + k->l + k->bsize;
+  for (int i = 0; i < k->qsize; ++i) t += k->q[i];
+  for (int i = 0; i < k->ssize; ++i) t += (long long)k->s[i] * (k->s[i] + 1) / 2;
+  for (int i = 0; i < k->cssize; ++i) t += (long long)k->cs[i] * k->cs[i];
+  t += 3LL * (k->ep + k->ed) + 3LL * k->psize;
+  return t;
+}
+
+// mirrors the checks of reference src/cones.c:583-700 (validate_cones) for the
+// cones carried here and REJECTS the ones that are not (complex PSD, exp, power)
+int validate_cone(const ScsCone *k, int m, bool verbose) {
+#define CONE_FAIL(msg)                                                                             \
+  do {                                                                                             \
+    if (verbose) printf("%s\n", msg);                                                              \
+    return -1;                                                                                     \
+  } while (0)
+  if (!k) CONE_FAIL("cone struct is NULL");
+  if (k->z < 0) CONE_FAIL("free cone dimension error");
+  if (k->l < 0) CONE_FAIL("lp cone dimension error");
+  if (k->bsize < 0) CONE_FAIL("box cone dimension error");
+  if (k->bsize > 1 && (!k->bl || !k->bu)) CONE_FAIL("box cone bounds missing");
+  for (int i = 0; i < k->bsize - 1; ++i)
+    if (k->bl[i] > k->bu[i]) CONE_FAIL("infeasible: box lower bound larger than upper bound");
+  if (k->qsize < 0 || (k->qsize > 0 && !k->q)) CONE_FAIL("soc cone dimension error");
+  for (int i = 0; i < k->qsize; ++i)
+    if (k->q[i] < 0) CONE_FAIL("soc cone dimension error");
+  if (k->ssize < 0 || (k->ssize > 0 && !k->s)) CONE_FAIL("sd cone dimension error");
+  for (int i = 0; i < k->ssize; ++i) {
+    if (k->s[i] < 0) CONE_FAIL("sd cone dimension error");
+    if (k->s[i] > PSD_K_LIMIT) CONE_FAIL("sd cone larger than 1024 x 1024 not supported by the MI355X backend");
+  }
+  if (k->cssize > 0) CONE_FAIL("complex PSD cones are not carried by the MI355X backend (out of scope)");
+  if (k->ep > 0 || k->ed > 0) CONE_FAIL("exponential cones are not carried by the MI355X backend (out of scope)");
+  if (k->psize > 0) CONE_FAIL("power cones are not carried by the MI355X backend (out of scope)");
+  if (cone_total_rows(k) != m) {
+    if (verbose)
+      printf("cone dimensions %lld not equal to num rows in A = m = %d\n", cone_total_rows(k), m);
+    return -1;
+  }
+  return 0;
+#undef CONE_FAIL
+}
+
+static inline int small_grid(long long len) {
+  long long g = (len + SCSAMD_BLOCK - 1) / SCSAMD_BLOCK;
+  return (int)std::max<long long>(1, std::min<long long>(g, 2048));
+}
+
+void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
+  m = m_;
+  stream = s;
+  z = k->z;
+  l = k->l;
+  bsize = k->bsize;
+  box_off = z + l;
+  int off = z + l;
+  if (bsize > 1) {
+    // normalize_box_cone (cones.c:1161-1177) applied to a private copy
+    std::vector<real> hl(bsize - 1), hu(bsize - 1);
+    const real *Db = D ? D + box_off : nullptr;
+    for (int j = 0; j < bsize - 1; ++j) {
+      const real f = Db ? Db[j + 1] / Db[0] : (real)1;
+      hu[j] = k->bu[j] >= (real)MAX_BOX_VAL ? (real)INFINITY : k->bu[j] * f;
+      hl[j] = k->bl[j] <= (real)-MAX_BOX_VAL ? (real)-INFINITY : k->bl[j] * f;
+    }
+    bl.alloc(bsize - 1);
+    bu.alloc(bsize - 1);
+    bl.upload(hl.data(), bsize - 1, stream);
+    bu.upload(hu.data(), bsize - 1, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  box_t.alloc(1);
+  {
+    const real one = 1; // cones.c:1560
+    box_t.upload(&one, 1, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  off += bsize;
+  // second-order cones
+  std::vector<int> toff, tlen, boff, blen, bt0, tcone, tileoff, tilelen;
+  for (int i = 0; i < k->qsize; ++i) {
+    const int q = k->q[i];
+    if (q <= SOC_TINY_MAX) {
+      toff.push_back(off);
+      tlen.push_back(q);
+    } else {
+      const int c = (int)boff.size();
+      boff.push_back(off);
+      blen.push_back(q);
+      bt0.push_back((int)tcone.size());
+      for (int o = 0; o < q; o += SOC_TILE) {
+        tcone.push_back(c);
+        tileoff.push_back(off + o);
+        tilelen.push_back(std::min(SOC_TILE, q - o));
+      }
+    }
+    off += q;
+  }
+  bt0.push_back((int)tcone.size());
+  n_tiny = (int)toff.size();
+  n_big = (int)boff.size();
+  n_tiles = (int)tcone.size();
+  auto up = [&](DevBuf<int> &d, std::vector<int> &h) {
+    d.alloc(h.size() ? h.size() : 1);
+    if (h.size()) d.upload(h.data(), h.size(), stream);
+  };
+  up(tiny_off, toff);
+  up(tiny_len, tlen);
+  up(big_off, boff);
+  up(big_len, blen);
+  up(big_tile0, bt0);
+  up(tile_cone, tcone);
+  up(tile_off, tileoff);
+  up(tile_len, tilelen);
+  tile_part.alloc(n_tiles ? n_tiles : 1);
+  big_coef.alloc(n_big ? 2 * (size_t)n_big : 2);
+  // PSD
+  std::vector<int> poff, pk;
+  psd_kmax = 0;
+  for (int i = 0; i < k->ssize; ++i) {
+    poff.push_back(off);
+    pk.push_back(k->s[i]);
+    psd_kmax = std::max(psd_kmax, k->s[i]);
+    off += k->s[i] * (k->s[i] + 1) / 2;
+  }
+  n_psd = (int)poff.size();
+  up(psd_off, poff);
+  up(psd_k, pk);
+  if (n_psd && psd_kmax > PSD_LDS_KMAX)
+    psd_work.alloc((size_t)n_psd * 2 * psd_kmax * (psd_kmax | 1));
+  status.alloc(1);
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (off != m) throw HipError("scs_amd: cone rows do not add up to m");
+}
+
+void ConeDev::proj_primal(real *cw, const real *r_y) {
+  if (z + l > 0)
+    hipLaunchKernelGGL(k_zero_pos, dim3(small_grid(z + l)), dim3(SCSAMD_BLOCK), 0, stream, cw, z, l);
+  if (bsize > 0)
+    hipLaunchKernelGGL(k_box, dim3(1), dim3(BOX_THREADS), 0, stream, cw + box_off, bl.p, bu.p, bsize,
+                       box_t.p, r_y ? r_y + box_off : (const real *)nullptr);
+  if (n_tiny)
+    hipLaunchKernelGGL(k_soc_tiny, dim3(small_grid(n_tiny)), dim3(SCSAMD_BLOCK), 0, stream, cw, tiny_off.p,
+                       tiny_len.p, n_tiny);
+  if (n_big) {
+    const int g = std::min(n_tiles, 8192);
+    hipLaunchKernelGGL(k_soc_tile_partial, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, cw, tile_off.p,
+                       tile_len.p, tile_cone.p, big_off.p, tile_part.p, n_tiles);
+    hipLaunchKernelGGL(k_soc_finalize, dim3(small_grid(n_big)), dim3(SCSAMD_BLOCK), 0, stream, cw,
+                       big_off.p, big_tile0.p, tile_part.p, big_coef.p, n_big);
+    hipLaunchKernelGGL(k_soc_tile_apply, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, cw, tile_off.p, tile_len.p,
+                       tile_cone.p, big_off.p, big_coef.p, n_tiles);
+  }
+  if (n_psd) {
+    const int use_lds = psd_kmax <= PSD_LDS_KMAX;
+    const size_t lds = PSD_LDS_HEADER + (use_lds ? (size_t)2 * psd_kmax * (psd_kmax | 1) * sizeof(real) : 0);
+    if (lds > 48 * 1024)
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_psd_jacobi),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
+                       psd_work.p, psd_kmax, use_lds, status.p);
+  }
+}
+
+void ConeDev::proj_dual(real *x, real *scratch, const real *r_y) {
+  const int g = small_grid(m);
+  hipLaunchKernelGGL(k_moreau_pre, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, x, scratch, r_y, m);
+  proj_primal(x, r_y);
+  hipLaunchKernelGGL(k_moreau_post, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, x, scratch, r_y, m);
+}
+
+} // namespace scsamd
+
+// ============================================================================
+// B1': host-pointer cone projection (replaces _scs_init_cone / _scs_proj_dual_cone /
+// _scs_finish_cone, reference include/cones.h:80-90)
+// ============================================================================
+using namespace scsamd;
+
+struct SCS_AMD_CONE_WORK {
+  ConeDev cd;
+  hipStream_t stream = nullptr;
+  ~SCS_AMD_CONE_WORK() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+extern "C" {
+
+ScsAmdConeWork *scs_amd_cone_init(const ScsCone *k, scs_int m, const scs_float *D) {
+  if (validate_cone(k, m, true) < 0) return nullptr;
+  ScsAmdConeWork *c = nullptr;
+  try {
+    c = new ScsAmdConeWork();
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->cd.init(k, m, D, c->stream);
+    c->cd.x_stage.alloc(m);
+    c->cd.s_stage.alloc(m);
+    c->cd.r_stage.alloc(m);
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+scs_int scs_amd_cone_proj_dual(ScsAmdConeWork *c, scs_float *x, const scs_float *r_y) {
+  if (!c || !x) return -1;
+  try {
+    ConeDev &cd = c->cd;
+    cd.x_stage.upload(x, cd.m, c->stream);
+    if (r_y) cd.r_stage.upload(r_y, cd.m, c->stream);
+    cd.proj_dual(cd.x_stage.p, cd.s_stage.p, r_y ? cd.r_stage.p : nullptr);
+    cd.x_stage.download(x, cd.m, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipGetLastError());
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
+  return 0;
+}
+
+void scs_amd_cone_finish(ScsAmdConeWork *c) { delete c; }
+
+} // extern "C"

@@ -24,9 +24,14 @@ constexpr int VEC_MAX_GRID = 2048;
 constexpr int PART_CAP = 4096; // >= SPMV_MAX_GRID and >= VEC_MAX_GRID
 
 static inline int vec_grid(long long len) {
+  static const int cap = [] {
+    const char *e = getenv("SCS_AMD_VEC_MAX_GRID"); // tests shrink it to force grid-striding
+    int g = e ? atoi(e) : VEC_MAX_GRID;
+    return (g >= 1 && g <= VEC_MAX_GRID) ? g : VEC_MAX_GRID;
+  }();
   long long g = (len + SCSAMD_BLOCK - 1) / SCSAMD_BLOCK;
   if (g < 1) g = 1;
-  if (g > VEC_MAX_GRID) g = VEC_MAX_GRID;
+  if (g > cap) g = cap;
   return (int)g;
 }
 
@@ -375,6 +380,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
                       real warm_scale) {
   const int gv = vec_grid(n), gnm = vec_grid((long long)n + m);
   CgCtl *c = ctl.p;
+  static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
   int cg_slot = -1;
   if (profiling) cg_slot = cg_timer.start(stream);
 
@@ -428,6 +434,10 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
     it += nb;
     HIP_CHECK(hipMemcpyAsync(hctl.p, c, sizeof(CgCtl), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    if (debug)
+      fprintf(stderr, "[scs_amd pcg] enq=%lld iters=%d done=%d zero=%d |r|=%.3e tol=%.3e ztr=(%.3e,%.3e) |b|=%.3e\n",
+              it, hctl.p->iters, hctl.p->cg_done, hctl.p->zero_rhs, (double)hctl.p->norm_r,
+              (double)hctl.p->tol, (double)hctl.p->ztr[0], (double)hctl.p->ztr[1], (double)hctl.p->rhs_norm);
     if (hctl.p->cg_done || it >= max_its) break;
     batch = std::max(4, std::min(last_its / 4 + 1, 1024));
   }
@@ -440,6 +450,16 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
   }
   if (profiling) cg_timer.stop(cg_slot, stream);
   HIP_CHECK(hipGetLastError());
+  if (const char *tf = getenv("SCS_AMD_TRACE_FILE")) { // same record as oracle/trace_linsys.c
+    real x0 = 0;
+    HIP_CHECK(hipMemcpyAsync(&x0, b, sizeof(real), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (FILE *f = fopen(tf, n_solves == 0 ? "w" : "a")) {
+      fprintf(f, "%lld tol=%.17g nb=%.17g its=%d x0=%.17g\n", n_solves, (double)hctl.p->tol,
+              (double)hctl.p->rhs_norm, its, (double)x0);
+      fclose(f);
+    }
+  }
   last_its = its;
   tot_cg_its += its;
   n_solves++;

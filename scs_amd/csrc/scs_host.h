@@ -1,0 +1,48 @@
+// scs_host.h -- host-side pieces shared by the B2 driver (setup-time only).
+#pragma once
+#include "common.h"
+
+namespace scsamd {
+
+typedef scs_float real;
+
+// owned host CSC copy (deep copy of the user's matrix; equilibrated in place)
+struct HostCsc {
+  int m = 0, n = 0;
+  std::vector<int> p, i;
+  std::vector<real> x;
+  void copy_from(const ScsMatrix *M) {
+    m = M->m;
+    n = M->n;
+    const size_t nnz = (size_t)M->p[M->n];
+    p.assign(M->p, M->p + M->n + 1);
+    i.assign(M->i, M->i + nnz);
+    x.assign(M->x, M->x + nnz);
+  }
+  ScsMatrix view() { return ScsMatrix{x.data(), i.data(), p.data(), m, n}; }
+};
+
+// reference include/scs_work.h:24-29 (ScsScaling)
+struct Scaling {
+  std::vector<real> D, E;
+  real primal_scale = 1, dual_scale = 1;
+};
+
+std::vector<int> cone_segments(const ScsCone *k);
+void equilibrate(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc);
+void normalize_b_c(Scaling &sc, real *b, real *c);
+void normalize_sol(const Scaling &sc, real *x, real *y, real *s);
+void un_normalize_sol(const Scaling &sc, real *x, real *y, real *s);
+int validate_csc(const ScsMatrix *M, int rows, int cols, bool upper_only, const char *name);
+
+// ---- host Anderson acceleration (reference include/aa.h:66-143) --------------
+struct AaHost;
+AaHost *aa_host_init(int dim, int mem, int min_len, int type1, real regularization, real relaxation,
+                     real safeguard_factor, real max_weight_norm, int ir_max_steps);
+real aa_host_apply(real *f, const real *x, AaHost *a);
+int aa_host_safeguard(real *f_new, real *x_new, AaHost *a);
+void aa_host_reset(AaHost *a);
+void aa_host_finish(AaHost *a);
+void aa_host_stats(const AaHost *a, AaStats *out);
+
+} // namespace scsamd

@@ -142,7 +142,8 @@ struct CsrDev {
   DevBuf<int> ptr, idx, rowblk;
   DevBuf<real> val;
   CsrView view() const { return CsrView{rows, cols, nblk, ptr.p, idx.p, val.p, rowblk.p}; }
-  int grid() const { return nblk < SPMV_MAX_GRID ? (nblk > 0 ? nblk : 1) : SPMV_MAX_GRID; }
+  int max_grid = SPMV_MAX_GRID; // tests shrink it (SCS_AMD_SPMV_MAX_GRID) to force grid-striding
+  int grid() const { return nblk < max_grid ? (nblk > 0 ? nblk : 1) : max_grid; }
   // algorithmic bytes of one product with this matrix:
   // nnz*(sf+si) + (rows+1)*si + cols*sf + rows*sf
   long long algorithmic_bytes() const {
@@ -155,6 +156,10 @@ struct CsrDev {
     rows = rows_;
     cols = cols_;
     nnz = hptr[rows_];
+    if (const char *e = getenv("SCS_AMD_SPMV_MAX_GRID")) {
+      int g = atoi(e);
+      if (g >= 1 && g <= SPMV_MAX_GRID) max_grid = g;
+    }
     ptr.alloc((size_t)rows + 1);
     idx.alloc((size_t)nnz);
     val.alloc((size_t)nnz);

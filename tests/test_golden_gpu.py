@@ -1,0 +1,59 @@
+"""HIP path vs the committed golden vectors (tests/golden/*.npz, produced by
+tests/golden/make_golden.py from the real reference).  No /root/reference needed."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from scs_amd import capi
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_linsys_boundary_vectors():
+    """(b, s, tol) -> [x; y] captured at the reference's scs_solve_lin_sys boundary."""
+    g = np.load(os.path.join(G, "linsys_cfg1.npz"))
+    n, m = int(g["n"]), int(g["m"])
+    A = sp.csc_matrix((g["Ax_normalized"], g["Ai"], g["Ap"]), shape=(m, n))
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
+    lib = capi.load("libscsamd_linsys.so")
+    T = lib._scs_types
+    dr = np.ascontiguousarray(g["diag_r"])
+    w = lib.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
+    assert w
+    for c in g["calls"]:
+        b = np.array(g[f"b{c}"])
+        s = np.array(g[f"s{c}"])
+        tol = float(g[f"tol{c}"])
+        want = g[f"xy{c}"]
+        rc = lib.scs_solve_lin_sys(w, b.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp) if len(s) else None, tol)
+        assert rc == 0
+        # same algorithm, same stopping rule: identical CG path up to summation order
+        err = np.abs(b - want).max() / max(np.abs(want).max(), 1e-300)
+        assert err <= 1e-9, (int(c), tol, err)
+    lib.scs_free_lin_sys_work(w)
+
+
+def test_cone_projection_vectors():
+    g = np.load(os.path.join(G, "cones.npz"))
+    meta = json.load(open(os.path.join(G, "cones_meta.json")))
+    lib = capi.load("libscsamd.so")
+    T = lib._scs_types
+    for name, cone in meta.items():
+        k = capi.make_cone(cone, T)
+        m = capi.cone_rows(cone)
+        w = lib.scs_amd_cone_init(C.byref(k), m, None)
+        assert w, name
+        for variant in ("eucl", "ry"):
+            x = np.array(g[f"{name}_{variant}_x"])
+            want = g[f"{name}_{variant}_y"]
+            r = np.array(g[f"{name}_{variant}_r"]) if variant == "ry" else None
+            rc = lib.scs_amd_cone_proj_dual(w, x.ctypes.data_as(T.fp), r.ctypes.data_as(T.fp) if r is not None else None)
+            assert rc == 0
+            err = np.abs(x - want).max() / max(1.0, np.abs(want).max())
+            assert err <= 1e-12 if "psd" not in name and name != "mixed" else err <= 1e-11, (name, variant, err)
+        lib.scs_amd_cone_finish(w)
