@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM iterations/sec of the MI355X-native SCS hot path.
+
+Metric (BASELINE.json): "ADMM iters/sec + time-to-eps=1e-4, 1e6-var random SOCP,
+1 GPU".  Workload at N=1: BASELINE configs[1] -- random SOCP n=1e6, m=2e6,
+nnz=1e7 (col_nnz=10), zero + nonnegative + second-order cones, fp64, indirect
+(PCG) linear solves, default SCS settings except acceleration_lookback=0 (Anderson
+acceleration is host-side by design and is reported separately).
+
+A "step" is ONE ADMM iteration (linear-system solve by PCG + cone projection +
+the vector glue) on inputs resident in HBM.  The run does W untimed warm-up
+iterations, then times EXACTLY K iterations between barrier+synchronize pairs,
+then (N=1) keeps iterating to eps=1e-4 to report time-to-eps.  With N>1 each rank
+solves its own independent problem of the same size (weak scaling; the path has
+no intra-solve collective -- RCCL only carries the batch descriptor and the
+result records).
+
+One JSON line on stdout (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--m", type=int, default=0, help="default 2n")
+    ap.add_argument("--col-nnz", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--aa", type=int, default=0, help="acceleration_lookback (0 = off)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-time-to-eps", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=100000)
+    ap.add_argument("--cpu-sample-iters", type=int, default=40)
+    ap.add_argument("--max-iters", type=int, default=20000)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, full_n):
+    """The reference's own CPU indirect solver (oracle/_ref, built from
+    /root/reference by oracle/Makefile) on the host cores, bounded sample."""
+    try:
+        from oracle import pyoracle
+        from scs_amd import capi, problems
+        if not pyoracle.ref_available():
+            return None
+        ref = pyoracle.load_ref("libscsindir_ref.so")
+        n = min(args.cpu_sample_n, full_n)
+        pr = problems.random_socp(n, 2 * n, args.col_nnz, seed=args.seed)
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+        t0 = time.time()
+        r = capi.solve(ref, prob, verbose=0, acceleration_lookback=args.aa, max_iters=args.cpu_sample_iters)
+        wall = time.time() - t0
+        info = r["info"]
+        its_per_s = info["iter"] / (info["solve_time"] / 1e3)
+        scale = n / float(full_n)
+        return dict(value=its_per_s * scale, unit="ADMM iters/sec", cores=1, kind="reference",
+                    sample=(f"reference libscsindir (linsys/cpu/indirect, 1 thread) on the same generator at "
+                            f"n={n}, m={2*n}, nnz={n*args.col_nnz}: first {info['iter']} ADMM iterations in "
+                            f"{info['solve_time']/1e3:.2f} s = {its_per_s:.3f} it/s, scaled by n_sample/n_full="
+                            f"{scale:g} (cost per iteration is linear in nnz)"),
+                    measured_it_per_s=its_per_s, sample_wall_s=wall, host_cores=os.cpu_count())
+    except Exception as e:  # the baseline is reported, never required
+        return dict(value=None, unit="ADMM iters/sec", cores=1, kind="reference", sample=f"unavailable: {e}")
+
+
+def main():
+    args = parse()
+    n = args.n
+    m = args.m or 2 * n
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group(backend="nccl")  # RCCL
+    from scs_amd import capi, problems
+    lib = capi.load("libscsamd.so")
+    T = lib._scs_types
+    assert lib.scs_amd_set_device(local_rank) == 0
+
+    # ---- batch descriptor: rank 0 decides, RCCL broadcast (launch) -------------
+    desc = torch.tensor([n, m, args.col_nnz, args.seed, args.steps, args.warmup, args.aa], dtype=torch.int64,
+                        device="cuda")
+    if dist:
+        dist.broadcast(desc, src=0)
+    n, m, col_nnz, seed, K, W, aa = [int(v) for v in desc.tolist()]
+
+    # ---- synthetic problem, one per rank (seed + rank) --------------------------
+    t0 = time.time()
+    pr = problems.random_socp(n, m, col_nnz, seed=seed + rank)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    t_gen = time.time() - t0
+    st = capi.default_settings(lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters)
+    t0 = time.time()
+    w = lib.scs_init(C.byref(prob.data), C.byref(prob.k), C.byref(st))
+    if not w:
+        raise SystemExit("scs_init failed")
+    t_init = time.time() - t0
+    x = np.zeros(n); y = np.zeros(m); s = np.zeros(m)
+    sol = T.ScsSolution(x.ctypes.data_as(T.fp), y.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp))
+    info = T.ScsInfo()
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up: everything scs_solve does before the loop + W iterations -----
+    t_solve0 = time.time()
+    assert lib.scs_amd_solve_begin(w, None, 0) == 0
+    it = lib.scs_amd_solve_steps(w, W)
+    assert it >= 0
+    stats0 = T.ScsAmdStats()
+    lib.scs_amd_get_stats(w, C.byref(stats0))
+    lib.scs_amd_set_profiling(w, 1)  # samples 1 in 8 SpMV launches with HIP events on OUR stream
+    # ---- timed region: exactly K ADMM iterations --------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    it2 = lib.scs_amd_solve_steps(w, K)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert it2 >= 0
+    steps_done = it2 - it
+    stats1 = T.ScsAmdStats()
+    lib.scs_amd_get_stats(w, C.byref(stats1))
+    lib.scs_amd_set_profiling(w, 0)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    steps_t = torch.tensor([steps_done], dtype=torch.int64, device="cuda")
+    if dist:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(steps_t, op=dist.ReduceOp.SUM)
+    elapsed_max = float(t_max.item())
+    total_steps = int(steps_t.item())
+
+    # ---- run on to eps = 1e-4 (time-to-eps), N = 1 only in the JSON -------------
+    tte = None
+    if not args.no_time_to_eps:
+        while not lib.scs_amd_solve_converged(w):
+            cur = lib.scs_amd_solve_steps(w, 100)
+            if cur < 0 or cur >= args.max_iters:
+                break
+        torch.cuda.synchronize()
+        tte = time.time() - t_solve0
+    lib.scs_amd_solve_end(w, C.byref(sol), C.byref(info))
+    res = capi.info_dict(info)
+
+    # ---- result records gathered over RCCL (collect) -----------------------------
+    rec = torch.tensor([res["status_val"], res["iter"], res["pobj"], res["dobj"], res["res_pri"], res["res_dual"],
+                        res["gap"], res["solve_time"]], dtype=torch.float64, device="cuda")
+    recs = [rec]
+    if dist:
+        recs = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(recs, rec)
+
+    if rank == 0:
+        cg_its = stats1.cg_iters - stats0.cg_iters
+        spmv_samples = stats1.spmv_launches - stats0.spmv_launches
+        spmv_ms = stats1.spmv_ms - stats0.spmv_ms
+        bytes_per_spmv = stats1.spmv_bytes / 2.0
+        roof = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
+                    kernel="csr_stream_kernel (CSR SpMV, both orientations)")
+        if spmv_samples > 0 and spmv_ms > 0:
+            avg_s = spmv_ms / spmv_samples * 1e-3
+            roof["achieved"] = bytes_per_spmv / avg_s / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+            roof["avg_launch_us"] = avg_s * 1e6
+            roof["algorithmic_bytes_per_launch"] = bytes_per_spmv
+            roof["launches_timed"] = int(spmv_samples)
+        out = {
+            "metric": "ADMM iters/sec (+ time-to-eps=1e-4), 1e6-var random SOCP, 1 GPU",
+            "value": total_steps / elapsed_max,
+            "unit": "ADMM iters/sec",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed_max / max(steps_done, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"random SOCP n={n} m={m} nnz={n*col_nnz} (BASELINE configs[1]); "
+                                   f"cones z={pr['cone']['z']} l={pr['cone']['l']} soc={len(pr['cone']['q'])}; "
+                                   f"indirect PCG; acceleration_lookback={aa}",
+                       "n": n, "m": m, "nnz": n * col_nnz, "problems_per_gpu": 1,
+                       "partition": "one independent problem per GPU"},
+            "roofline": roof,
+            "cg_its_per_admm_iter": cg_its / max(steps_done, 1),
+            "time_to_eps_s": tte,
+            "iters_to_eps": res["iter"] if res["status_val"] == 1 else None,
+            "status": res["status"],
+            "final": {k: res[k] for k in ("pobj", "dobj", "res_pri", "res_dual", "gap", "iter")},
+            "setup_s": {"generate": t_gen, "scs_init": t_init},
+            "results_per_rank": [[float(v) for v in r.tolist()] for r in recs],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, n)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    lib.scs_finish(w)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

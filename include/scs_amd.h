@@ -247,6 +247,20 @@ void scs_amd_linsys_get_stats(const ScsLinSysWork *w, ScsAmdStats *out);
 void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on);
 void scs_amd_get_stats(const ScsWork *w, ScsAmdStats *out);
 void scs_amd_set_profiling(ScsWork *w, scs_int on);
+/* scs_solve split in three so a harness can time / inspect an exact range of ADMM
+ * iterations (bench.py's timed region, trajectory tests):
+ *   scs_amd_solve_begin(w, sol_or_NULL, warm)   == everything scs_solve does before
+ *                                                  the loop (src/scs.c:1341-1354)
+ *   scs_amd_solve_steps(w, k)                   runs up to k more iterations, returns
+ *                                                  the iteration counter, stream idle
+ *   scs_amd_solve_end(w, sol, info)             == finalize + timings (:1457-1484)   */
+scs_int scs_amd_solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start);
+scs_int scs_amd_solve_steps(ScsWork *w, scs_int steps);
+scs_int scs_amd_solve_converged(const ScsWork *w);
+scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
+/* test hook: every per-iteration linear solve uses this tolerance instead of the
+ * schedule of src/scs.c:745-762 (0 restores the schedule) */
+void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
 /* number of visible HIP devices, or <0 with no usable runtime (never throws) */
 scs_int scs_amd_device_count(void);
 /* select the device used by subsequently created workspaces (default 0) */

@@ -145,6 +145,16 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             lib.scs_amd_get_stats.argtypes = [C.c_void_p, C.POINTER(T.ScsAmdStats)]
             lib.scs_amd_set_profiling.restype = None
             lib.scs_amd_set_profiling.argtypes = [C.c_void_p, scs_int]
+            lib.scs_amd_solve_begin.restype = scs_int
+            lib.scs_amd_solve_begin.argtypes = [C.c_void_p, C.POINTER(T.ScsSolution), scs_int]
+            lib.scs_amd_solve_steps.restype = scs_int
+            lib.scs_amd_solve_steps.argtypes = [C.c_void_p, scs_int]
+            lib.scs_amd_solve_converged.restype = scs_int
+            lib.scs_amd_solve_converged.argtypes = [C.c_void_p]
+            lib.scs_amd_solve_end.restype = scs_int
+            lib.scs_amd_solve_end.argtypes = [C.c_void_p, C.POINTER(T.ScsSolution), C.POINTER(T.ScsInfo)]
+            lib.scs_amd_set_cg_tol_override.restype = None
+            lib.scs_amd_set_cg_tol_override.argtypes = [C.c_void_p, C.c_double]
     lib._scs_types = T
     return lib
 

@@ -372,6 +372,10 @@ struct SCS_WORK {
   std::vector<real> hv, hv_prev;
   real aa_norm = 0;
   int rejected_accel_steps = 0, accepted_accel_steps = 0;
+  // solve state (scs_solve = solve_begin + solve_steps + solve_end)
+  int cur_iter = 0, run_status = SCS_UNFINISHED;
+  bool loop_done = false, stepped = false;
+  double t_solve0 = 0, t_lin = 0, t_accel = 0, cg_tol_override = 0;
   // instrumentation
   EventTimer cone_timer;
   bool profiling = false;
@@ -666,7 +670,7 @@ static void set_unfinished(const ScsWork *w, ScsSolution *sol, ScsInfo *info) {
     info->status_val = SCS_FAILED;
   }
   if (w->time_limit_reached) strcat(info->status, " (inaccurate - reached time_limit_secs)");
-  else if (info->iter >= w->stgs.max_iters) strcat(info->status, " (inaccurate - reached max_iters)");
+  else if (info->iter >= w->stgs.max_iters || w->stepped) strcat(info->status, " (inaccurate - reached max_iters)");
   else printf("ERROR: should not be in this state (1).\n");
 }
 
@@ -893,160 +897,174 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
   return w;
 }
 
-scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start) { // :1327-1484
-  if (!sol || !w || !info) {
-    printf("ERROR: missing ScsWork, ScsSolution or ScsInfo input\n");
-    return SCS_FAILED;
-  }
+// The solve is split in three so that instrumentation (bench.py, trajectory tests)
+// can time / inspect an exact range of iterations; scs_solve is begin + steps + end.
+static void solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) {
   const int n = w->n, m = w->m, l = w->l;
   hipStream_t st = w->stream;
-  const double t_solve = now_ms();
-  double t_lin = 0, t_accel = 0;
+  w->t_solve0 = now_ms();
+  w->t_lin = w->t_accel = 0;
   w->cone_timer.total_ms = 0;
   w->cone_timer.samples = 0;
-  int i = 0;
-  try {
-    w->stgs.warm_start = warm_start;
-    strcpy(info->lin_sys_solver, scs_get_lin_sys_method());
-    info->status_val = SCS_UNFINISHED;
-    // reset_tracking (:1131-1144)
-    w->last_scale_update_iter = 0;
-    w->sum_log_scale_factor = 0;
-    w->n_log_scale_factor = 0;
-    w->scale_updates = 0;
-    w->time_limit_reached = 0;
-    w->rejected_accel_steps = w->accepted_accel_steps = 0;
-    w->aa_norm = 0;
-    w->r_n = Resid();
-    w->r_o = Resid();
-    // warm / cold start (:660-687)
-    {
-      std::vector<real> hv(l, (real)0);
-      if (warm_start && sol->x && sol->y && sol->s) {
-        std::vector<real> x(sol->x, sol->x + n), y(sol->y, sol->y + m), s(sol->s, sol->s + m);
-        if (w->stgs.normalize) normalize_sol(w->scal, x.data(), y.data(), s.data());
-        std::vector<real> hr(l);
-        w->diag_r.download(hr.data(), l, st);
-        HIP_CHECK(hipStreamSynchronize(st));
-        for (int j = 0; j < n; ++j) hv[j] = x[j] != x[j] ? (real)0 : x[j];
-        for (int j = 0; j < m; ++j) {
-          real t = y[j] + s[j] / hr[n + j];
-          hv[n + j] = t != t ? (real)0 : t;
-        }
-      }
-      hv[l - 1] = 1;
-      w->v.upload(hv.data(), l, st);
-      HIP_CHECK(hipMemsetAsync(w->u.p, 0, l * sizeof(real), st));
-      HIP_CHECK(hipMemsetAsync(w->u_t.p, 0, l * sizeof(real), st));
-      HIP_CHECK(hipMemsetAsync(w->rsk.p, 0, l * sizeof(real), st));
-      HIP_CHECK(hipStreamSynchronize(st));
+  w->cur_iter = 0;
+  w->run_status = SCS_UNFINISHED;
+  w->loop_done = false;
+  w->stepped = false;
+  w->stgs.warm_start = warm_start;
+  // reset_tracking (:1131-1144)
+  w->last_scale_update_iter = 0;
+  w->sum_log_scale_factor = 0;
+  w->n_log_scale_factor = 0;
+  w->scale_updates = 0;
+  w->time_limit_reached = 0;
+  w->rejected_accel_steps = w->accepted_accel_steps = 0;
+  w->aa_norm = 0;
+  w->r_n = Resid();
+  w->r_o = Resid();
+  // warm / cold start (:660-687)
+  std::vector<real> hv(l, (real)0);
+  if (warm_start && sol && sol->x && sol->y && sol->s) {
+    std::vector<real> x(sol->x, sol->x + n), y(sol->y, sol->y + m), s(sol->s, sol->s + m);
+    if (w->stgs.normalize) normalize_sol(w->scal, x.data(), y.data(), s.data());
+    std::vector<real> hr(l);
+    w->diag_r.download(hr.data(), l, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int j = 0; j < n; ++j) hv[j] = x[j] != x[j] ? (real)0 : x[j];
+    for (int j = 0; j < m; ++j) {
+      real t = y[j] + s[j] / hr[n + j];
+      hv[n + j] = t != t ? (real)0 : t;
     }
-    if (w->accel) aa_host_reset(w->accel);
-    update_work_cache(w);
-    if (w->stgs.verbose) print_header(w);
+  }
+  hv[l - 1] = 1;
+  w->v.upload(hv.data(), l, st);
+  HIP_CHECK(hipMemsetAsync(w->u.p, 0, l * sizeof(real), st));
+  HIP_CHECK(hipMemsetAsync(w->u_t.p, 0, l * sizeof(real), st));
+  HIP_CHECK(hipMemsetAsync(w->rsk.p, 0, l * sizeof(real), st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (w->accel) aa_host_reset(w->accel);
+  update_work_cache(w);
+  if (w->stgs.verbose) print_header(w);
+}
 
-    const int gl = glue_grid(l), gnm = glue_grid(n + m);
-    real *rp_part = w->part.p; // root_plus partials reuse the residual partial area (5 rows)
-    for (i = 0; i < w->stgs.max_iters; ++i) {
-      // ---- Anderson acceleration (host) :1359-1366
-      if (w->accel) {
-        const double ta = now_ms();
-        if (i > 0 && i % w->stgs.acceleration_interval == 0) {
-          w->v.download(w->hv.data(), l, st);
-          w->v_prev.download(w->hv_prev.data(), l, st);
-          HIP_CHECK(hipStreamSynchronize(st));
-          w->aa_norm = aa_host_apply(w->hv.data(), w->hv_prev.data(), w->accel);
-          w->v.upload(w->hv.data(), l, st);
-          HIP_CHECK(hipStreamSynchronize(st));
-        }
-        t_accel += now_ms() - ta;
-      }
-      // ---- normalize v, v_prev, u_t, warm start :1368-1377, :738-758
-      const int do_norm = i >= FEASIBLE_ITERS;
-      if (do_norm) hipLaunchKernelGGL(k_sumsq_partial, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p, l, w->part.p + 8 * PSTRIDE);
-      hipLaunchKernelGGL(k_prep_linsys, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p,
-                         w->accel ? w->v_prev.p : (real *)nullptr, w->u_t.p, w->u.p, w->g.p, w->diag_r.p,
-                         w->warm.p, n, l, w->part.p + 8 * PSTRIDE, gl, w->part.p + 9 * PSTRIDE, do_norm);
-      // ---- linear system :763 with the tolerance schedule of :745-762
-      {
-        const double tl = now_ms();
-        const real tol_cap = std::min(w->r_n.nm_ax_s_btau, w->r_n.nm_px_aty_ctau);
-        const real warm_scale = (real)1.0 / std::pow((real)i + 1, (real)CG_RATE);
-        w->ls.solve_dev(w->u_t.p, w->warm.p, tol_cap, w->part.p + 9 * PSTRIDE, gl, warm_scale);
-        t_lin += now_ms() - tl;
-      }
-      // ---- tau~, u_t, u = 2 u_t - v, Moreau pre :764-769, :796-800
-      const int feas = i < FEASIBLE_ITERS;
-      if (!feas)
-        hipLaunchKernelGGL(k_root_plus_partial, dim3(gnm), dim3(SCSAMD_BLOCK), 0, st, w->u_t.p, w->v.p, w->g.p,
-                           w->diag_r.p, n + m, rp_part, PSTRIDE);
-      hipLaunchKernelGGL(k_post_linsys, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->u_t.p, w->u.p, w->v.p, w->g.p,
-                         w->diag_r.p, w->cw.p, n, l, rp_part, gnm, PSTRIDE, feas);
-      // ---- cone projection :803
-      int cslot = -1;
-      if (w->cone_timer.used < 500) cslot = w->cone_timer.start(st);
-      w->cone.proj_primal(w->cw.p, w->diag_r.p + n);
-      w->cone_timer.stop(cslot, st);
-      w->cone_projs++;
-      // ---- rsk (+ dual update when nothing can intervene) :1397, :1432
-      const bool check = i % CONVERGED_INTERVAL == 0;
-      const bool print = w->stgs.verbose && i % PRINT_INTERVAL == 0;
-      const bool fuse_dual = !check && !print;
-      hipLaunchKernelGGL(k_post_cone, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->u.p, w->u_t.p, w->v.p, w->rsk.p,
-                         w->diag_r.p, w->cw.p, n, l, fuse_dual ? w->stgs.alpha : (real)0);
-      if (check) {
-        populate_residuals(w, i);
-        if ((info->status_val = has_converged(w)) != 0) break;
-        if (w->stgs.time_limit_secs && now_ms() - t_solve > 1000. * w->stgs.time_limit_secs) {
-          w->time_limit_reached = 1;
-          break;
-        }
-      }
-      if (print) {
-        populate_residuals(w, i);
-        print_summary(w, i, t_solve);
-      }
-      if (w->stgs.adaptive_scale && i == w->r_o.last_iter) {
-        if (update_scale(w, i) < 0)
-          return fail_out(w, m, n, sol, info, SCS_FAILED, "error in update_scale", "failure");
-      }
-      if (!fuse_dual)
-        hipLaunchKernelGGL(k_dual_update, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p, w->u.p, w->u_t.p, l,
-                           w->stgs.alpha);
-      // ---- AA safeguard :1439-1447
-      if (w->accel && i % w->stgs.acceleration_interval == 0 && w->aa_norm > 0) {
-        const double ta = now_ms();
+// run iterations [cur_iter, upto) of the loop of src/scs.c:1356-1455; stops early on
+// convergence / time limit (loop_done).  Returns <0 on failure.
+static int solve_steps(ScsWork *w, int upto) {
+  const int n = w->n, m = w->m, l = w->l;
+  hipStream_t st = w->stream;
+  const int gl = glue_grid(l), gnm = glue_grid(n + m);
+  real *rp_part = w->part.p; // root_plus partials reuse the residual partial area (5 rows)
+  int &i = w->cur_iter;
+  for (; i < upto && !w->loop_done; ++i) {
+    // ---- Anderson acceleration (host) :1359-1366
+    if (w->accel) {
+      const double ta = now_ms();
+      if (i > 0 && i % w->stgs.acceleration_interval == 0) {
         w->v.download(w->hv.data(), l, st);
         w->v_prev.download(w->hv_prev.data(), l, st);
         HIP_CHECK(hipStreamSynchronize(st));
-        if (aa_host_safeguard(w->hv.data(), w->hv_prev.data(), w->accel) < 0) {
-          w->rejected_accel_steps++;
-          w->v.upload(w->hv.data(), l, st);
-          w->v_prev.upload(w->hv_prev.data(), l, st);
-          HIP_CHECK(hipStreamSynchronize(st));
-        } else {
-          w->accepted_accel_steps++;
-        }
-        t_accel += now_ms() - ta;
+        w->aa_norm = aa_host_apply(w->hv.data(), w->hv_prev.data(), w->accel);
+        w->v.upload(w->hv.data(), l, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
+      w->t_accel += now_ms() - ta;
+    }
+    // ---- normalize v, v_prev, u_t, warm start :1368-1377, :738-758
+    const int do_norm = i >= FEASIBLE_ITERS;
+    if (do_norm)
+      hipLaunchKernelGGL(k_sumsq_partial, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p, l, w->part.p + 8 * PSTRIDE);
+    hipLaunchKernelGGL(k_prep_linsys, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p,
+                       w->accel ? w->v_prev.p : (real *)nullptr, w->u_t.p, w->u.p, w->g.p, w->diag_r.p,
+                       w->warm.p, n, l, w->part.p + 8 * PSTRIDE, gl, w->part.p + 9 * PSTRIDE, do_norm);
+    // ---- linear system :763 with the tolerance schedule of :745-762
+    {
+      const double tl = now_ms();
+      const real warm_scale = (real)1.0 / std::pow((real)i + 1, (real)CG_RATE);
+      if (w->cg_tol_override > 0) {
+        w->ls.solve_dev(w->u_t.p, w->warm.p, (real)w->cg_tol_override);
+      } else {
+        const real tol_cap = std::min(w->r_n.nm_ax_s_btau, w->r_n.nm_px_aty_ctau);
+        w->ls.solve_dev(w->u_t.p, w->warm.p, tol_cap, w->part.p + 9 * PSTRIDE, gl, warm_scale);
+      }
+      w->t_lin += now_ms() - tl;
+    }
+    // ---- tau~, u_t, u = 2 u_t - v, Moreau pre :764-769, :796-800
+    const int feas = i < FEASIBLE_ITERS;
+    if (!feas)
+      hipLaunchKernelGGL(k_root_plus_partial, dim3(gnm), dim3(SCSAMD_BLOCK), 0, st, w->u_t.p, w->v.p, w->g.p,
+                         w->diag_r.p, n + m, rp_part, PSTRIDE);
+    hipLaunchKernelGGL(k_post_linsys, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->u_t.p, w->u.p, w->v.p, w->g.p,
+                       w->diag_r.p, w->cw.p, n, l, rp_part, gnm, PSTRIDE, feas);
+    // ---- cone projection :803
+    int cslot = -1;
+    if (w->cone_timer.used < 500) cslot = w->cone_timer.start(st);
+    w->cone.proj_primal(w->cw.p, w->diag_r.p + n);
+    w->cone_timer.stop(cslot, st);
+    w->cone_projs++;
+    // ---- rsk (+ dual update when nothing can intervene) :1397, :1432
+    const bool check = i % CONVERGED_INTERVAL == 0;
+    const bool print = w->stgs.verbose && i % PRINT_INTERVAL == 0;
+    const bool fuse_dual = !check && !print;
+    hipLaunchKernelGGL(k_post_cone, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->u.p, w->u_t.p, w->v.p, w->rsk.p,
+                       w->diag_r.p, w->cw.p, n, l, fuse_dual ? w->stgs.alpha : (real)0);
+    if (check) {
+      populate_residuals(w, i);
+      if ((w->run_status = has_converged(w)) != 0) {
+        w->loop_done = true;
+        break; // like the reference, the converged iteration is not counted (:1405-1407)
+      }
+      if (w->stgs.time_limit_secs && now_ms() - w->t_solve0 > 1000. * w->stgs.time_limit_secs) {
+        w->time_limit_reached = 1;
+        w->loop_done = true;
+        break;
       }
     }
-    if (w->stgs.verbose) {
+    if (print) {
       populate_residuals(w, i);
-      print_summary(w, i, t_solve);
+      print_summary(w, i, w->t_solve0);
     }
-    finalize(w, sol, info, i);
-    HIP_CHECK(hipGetLastError());
-  } catch (const std::exception &ex) {
-    fprintf(stderr, "%s\n", ex.what());
-    return fail_out(w, m, n, sol, info, SCS_FAILED, "HIP error in scs_solve", "failure");
+    if (w->stgs.adaptive_scale && i == w->r_o.last_iter) {
+      if (update_scale(w, i) < 0) return -1;
+    }
+    if (!fuse_dual)
+      hipLaunchKernelGGL(k_dual_update, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p, w->u.p, w->u_t.p, l,
+                         w->stgs.alpha);
+    // ---- AA safeguard :1439-1447
+    if (w->accel && i % w->stgs.acceleration_interval == 0 && w->aa_norm > 0) {
+      const double ta = now_ms();
+      w->v.download(w->hv.data(), l, st);
+      w->v_prev.download(w->hv_prev.data(), l, st);
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (aa_host_safeguard(w->hv.data(), w->hv_prev.data(), w->accel) < 0) {
+        w->rejected_accel_steps++;
+        w->v.upload(w->hv.data(), l, st);
+        w->v_prev.upload(w->hv_prev.data(), l, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+      } else {
+        w->accepted_accel_steps++;
+      }
+      w->t_accel += now_ms() - ta;
+    }
   }
+  return 0;
+}
+
+static void solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info) {
+  const int i = w->cur_iter;
+  strcpy(info->lin_sys_solver, scs_get_lin_sys_method());
+  info->status_val = w->run_status;
+  if (w->stgs.verbose) {
+    populate_residuals(w, i);
+    print_summary(w, i, w->t_solve0);
+  }
+  finalize(w, sol, info, i);
+  HIP_CHECK(hipGetLastError());
   w->cone_timer.harvest();
-  info->solve_time = (real)(now_ms() - t_solve);
-  info->lin_sys_time = (real)t_lin;
+  info->solve_time = (real)(now_ms() - w->t_solve0);
+  info->lin_sys_time = (real)w->t_lin;
   info->cone_time = (real)(w->cone_timer.samples
                                ? w->cone_timer.total_ms * ((double)std::max(i, 1) / (double)w->cone_timer.samples)
                                : 0.0);
-  info->accel_time = (real)t_accel;
+  info->accel_time = (real)w->t_accel;
   if (w->stgs.verbose) {
     printf("------------------------------------------------------------------\n");
     printf("status:  %s\n", info->status);
@@ -1058,7 +1076,68 @@ scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_star
     printf("objective = %.6f, iters %d, cg its %lld\n", (double)info->pobj, (int)info->iter, w->ls.tot_cg_its);
     printf("------------------------------------------------------------------\n");
   }
+}
+
+scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start) { // :1327-1484
+  if (!sol || !w || !info) {
+    printf("ERROR: missing ScsWork, ScsSolution or ScsInfo input\n");
+    return SCS_FAILED;
+  }
+  try {
+    solve_begin(w, sol, warm_start);
+    if (solve_steps(w, w->stgs.max_iters) < 0)
+      return fail_out(w, w->m, w->n, sol, info, SCS_FAILED, "error in update_scale", "failure");
+    solve_end(w, sol, info);
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return fail_out(w, w->m, w->n, sol, info, SCS_FAILED, "HIP error in scs_solve", "failure");
+  }
   return info->status_val;
+}
+
+// ---- instrumentation: the same solve in three calls (not in the reference) ------
+scs_int scs_amd_solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) {
+  if (!w) return -1;
+  try {
+    solve_begin(w, sol, warm_start);
+    HIP_CHECK(hipStreamSynchronize(w->stream));
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
+  return 0;
+}
+// Runs up to `steps` further ADMM iterations; returns the iteration counter
+// afterwards (it stops advancing once converged), or <0 on failure.  The stream is
+// idle on return.
+scs_int scs_amd_solve_steps(ScsWork *w, scs_int steps) {
+  if (!w) return -1;
+  try {
+    w->stepped = true;
+    const long long upto = std::min<long long>((long long)w->cur_iter + steps, w->stgs.max_iters);
+    if (solve_steps(w, (int)upto) < 0) return -1;
+    HIP_CHECK(hipStreamSynchronize(w->stream));
+    HIP_CHECK(hipGetLastError());
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
+  return w->cur_iter;
+}
+scs_int scs_amd_solve_converged(const ScsWork *w) { return w ? (w->loop_done ? 1 : 0) : -1; }
+scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info) {
+  if (!w || !sol || !info) return SCS_FAILED;
+  try {
+    solve_end(w, sol, info);
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return fail_out(w, w->m, w->n, sol, info, SCS_FAILED, "HIP error in scs_solve", "failure");
+  }
+  return info->status_val;
+}
+// test hook: force every per-iteration linear solve to this tolerance (0 = schedule)
+void scs_amd_set_cg_tol_override(ScsWork *w, double tol) {
+  if (w) w->cg_tol_override = tol;
 }
 
 void scs_finish(ScsWork *w) { delete w; }
