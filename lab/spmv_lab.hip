@@ -1,0 +1,214 @@
+// lab/spmv_lab.hip -- micro-experiments behind the SpMV design (not product code).
+// Builds a cfg2-shaped random matrix (n cols, m=2n rows, col_nnz per column) and
+// times: (1) a pure streaming copy, (2) random 8-byte gathers from tables of
+// varying footprint, (3) the csr_stream kernel variants in both orientations.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 lab/spmv_lab.hip -o lab/spmv_lab
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <typename T> T *dev(const std::vector<T> &h) {
+  T *p; CK(hipMalloc(&p, (h.size() + 64) * sizeof(T)));
+  CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return p;
+}
+template <typename T> T *devz(size_t n) { T *p; CK(hipMalloc(&p, (n + 64) * sizeof(T))); CK(hipMemset(p, 0, (n + 64) * sizeof(T))); return p; }
+
+template <typename F> double time_us(F f, int reps = 20) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) f();
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return 1e3 * ms / reps;
+}
+
+// ---- (1) streaming copy ------------------------------------------------------
+__global__ void k_copy(const double2 *__restrict__ a, double2 *b, size_t n2) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+// ---- (1b) stream val+idx and reduce (no gather) ----------------------------------
+template <int NT> __global__ void k_stream(const double *__restrict__ val, const int *__restrict__ idx, double *out, size_t nnz) {
+  double acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
+    double v = NT ? __builtin_nontemporal_load(val + i) : val[i];
+    int c = NT ? __builtin_nontemporal_load(idx + i) : idx[i];
+    acc += v * (double)(c & 1);
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+// ---- (2) random gathers from a table of `tab` doubles ---------------------------
+template <int NT, int U> __global__ void k_gather(const int *__restrict__ idx, const double *__restrict__ x, double *out, size_t nnz, int mask) {
+  double acc = 0;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + (U - 1) * stride < nnz; i += U * stride) {
+    int c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) c[u] = (NT ? __builtin_nontemporal_load(idx + i + u * stride) : idx[i + u * stride]) & mask;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += x[c[u]];
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+// cache-policy variants of the 8-byte gather: 0 plain, 1 nt builtin, 2 sc1, 3 sc0 sc1, 4 nt asm
+template <int POL> __device__ __forceinline__ double gload(const double *p) {
+  if (POL == 0) return *p;
+  if (POL == 1) return __builtin_nontemporal_load(p);
+  double v;
+  if (POL == 2) asm volatile("global_load_dwordx2 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  if (POL == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  if (POL == 4) asm volatile("global_load_dwordx2 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int POL> __global__ void k_gather_pol(const int *__restrict__ idx, const double *x, double *out, size_t nnz, int mask) {
+  double acc = 0;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += stride) acc += gload<POL>(x + (idx[i] & mask));
+  if (acc == 12345.678) out[0] = acc;
+}
+
+// ---- (3) csr_stream variants --------------------------------------------------------
+struct Csr { int rows, cols, nblk; const int *ptr, *idx, *rowblk; const double *val; };
+// FLAGS: bit0 = nontemporal streams, bit1 = skip gather (x[0]), bit2 = skip phase 2
+template <int NNZB, int BLOCK, int FLAGS>
+__global__ __launch_bounds__(BLOCK) void k_csr_stream(Csr A, const double *__restrict__ x, double *y) {
+  __shared__ double prod[NNZB];
+  constexpr int U = NNZB / BLOCK;
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < A.nblk; b += gridDim.x) {
+    const int r0 = A.rowblk[b], r1 = A.rowblk[b + 1];
+    const int k0 = A.ptr[r0], cnt = A.ptr[r1] - k0;
+    int ii[U]; double vv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int k = tid + j * BLOCK; const bool ok = k < cnt;
+      if (FLAGS & 1) { ii[j] = ok ? __builtin_nontemporal_load(A.idx + k0 + k) : 0; vv[j] = ok ? __builtin_nontemporal_load(A.val + k0 + k) : 0.0; }
+      else { ii[j] = ok ? A.idx[k0 + k] : 0; vv[j] = ok ? A.val[k0 + k] : 0.0; }
+    }
+    double xx[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) xx[j] = (FLAGS & 2) ? x[ii[j] & 1] : x[ii[j]];
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int k = tid + j * BLOCK; if (k < cnt) prod[k] = vv[j] * xx[j]; }
+    __syncthreads();
+    if (!(FLAGS & 4)) {
+      for (int r = r0 + tid; r < r1; r += BLOCK) {
+        const int a = A.ptr[r] - k0, z = A.ptr[r + 1] - k0;
+        double acc = 0;
+        for (int k = a; k < z; ++k) acc += prod[k];
+        if (FLAGS & 8) y[r] += acc; else y[r] = acc;
+      }
+    } else if (tid == 0) y[r0] = prod[0];
+    __syncthreads();
+  }
+}
+
+// wave-per-chunk variant without LDS: each lane owns a contiguous run of rows? (row-per-lane, "scalar CSR")
+__global__ __launch_bounds__(256) void k_csr_scalar(Csr A, const double *__restrict__ x, double *y) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < A.rows; r += gridDim.x * blockDim.x) {
+    double acc = 0;
+    const int a = A.ptr[r], z = A.ptr[r + 1];
+    for (int k = a; k < z; ++k) acc += A.val[k] * x[A.idx[k]];
+    y[r] = acc;
+  }
+}
+
+static void build_rowblk(int rows, const std::vector<int> &ptr, int nnzb, int rowsmax, std::vector<int> &rb) {
+  rb.clear(); rb.push_back(0); int r = 0;
+  while (r < rows) { int s = r; long long acc = 0;
+    while (r < rows && r - s < rowsmax) { long long rn = ptr[r + 1] - ptr[r]; if (acc + rn > nnzb) break; acc += rn; ++r; }
+    if (r == s) ++r; rb.push_back(r); }
+}
+
+int main(int argc, char **argv) {
+  int n = argc > 1 ? atoi(argv[1]) : 1000000; int cn = argc > 2 ? atoi(argv[2]) : 10; int m = 2 * n;
+  size_t nnz = (size_t)n * cn;
+  printf("n=%d m=%d nnz=%zu\n", n, m, nnz);
+  std::mt19937_64 rng(1);
+  // CSC(A) = CSR(A'): n rows, exactly cn sorted distinct entries each, cols in [0,m)
+  std::vector<int> Tp(n + 1), Ti(nnz); std::vector<double> Tx(nnz);
+  for (int j = 0; j < n; ++j) { Tp[j] = j * cn; int *r = &Ti[(size_t)j * cn];
+    for (;;) { for (int k = 0; k < cn; ++k) r[k] = (int)(rng() % m); std::sort(r, r + cn); if (std::adjacent_find(r, r + cn) == r + cn) break; }
+    for (int k = 0; k < cn; ++k) Tx[(size_t)j * cn + k] = (double)(rng() % 2001) / 1000.0 - 1.0; }
+  Tp[n] = (int)nnz;
+  // transpose -> CSR(A): m rows
+  std::vector<int> Ap(m + 1, 0), Ai(nnz); std::vector<double> Ax(nnz);
+  for (size_t k = 0; k < nnz; ++k) Ap[Ti[k] + 1]++;
+  for (int i = 0; i < m; ++i) Ap[i + 1] += Ap[i];
+  { std::vector<int> nx(Ap.begin(), Ap.end() - 1);
+    for (int j = 0; j < n; ++j) for (int k = Tp[j]; k < Tp[j + 1]; ++k) { int q = nx[Ti[k]]++; Ai[q] = j; Ax[q] = Tx[k]; } }
+  std::vector<double> hx(m); for (auto &v : hx) v = (double)(rng() % 1000) / 1000.0;
+
+  int *dTp = dev(Tp), *dTi = dev(Ti), *dAp = dev(Ap), *dAi = dev(Ai);
+  double *dTx = dev(Tx), *dAx = dev(Ax), *dxm = dev(hx), *dy = devz<double>(m), *dout = devz<double>(16);
+
+  // (1) copy
+  { size_t n2 = nnz / 2; double us = time_us([&] { hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, 0, (const double2 *)dTx, (double2 *)dy == nullptr ? nullptr : (double2 *)dAx, n2); });
+    printf("copy 2x%.0f MB: %.1f us  %.0f GB/s\n", nnz * 8 / 1e6, us, 2.0 * nnz * 8 / us / 1e3); }
+  { double us = time_us([&] { hipLaunchKernelGGL((k_stream<0>), dim3(4096), dim3(256), 0, 0, dTx, dTi, dout, nnz); });
+    printf("stream val+idx (120 MB): %.1f us  %.0f GB/s\n", us, nnz * 12.0 / us / 1e3);
+    us = time_us([&] { hipLaunchKernelGGL((k_stream<1>), dim3(4096), dim3(256), 0, 0, dTx, dTi, dout, nnz); });
+    printf("stream val+idx nt      : %.1f us  %.0f GB/s\n", us, nnz * 12.0 / us / 1e3); }
+  // (2) gathers vs footprint
+  for (int lg = 17; lg <= 21; ++lg) { int mask = (1 << lg) - 1; if (mask >= m) mask = (1 << 20) - 1;
+    double us = time_us([&] { hipLaunchKernelGGL((k_gather<0, 8>), dim3(4096), dim3(256), 0, 0, dTi, dxm, dout, nnz, mask); });
+    double us2 = time_us([&] { hipLaunchKernelGGL((k_gather<1, 8>), dim3(4096), dim3(256), 0, 0, dTi, dxm, dout, nnz, mask); });
+    printf("gather 1e7 x 8B from %5.1f MB table: %.1f us (%.1f Ggather/s) ; nt idx %.1f us\n", (mask + 1) * 8 / 1e6, us, nnz / us / 1e3, us2); }
+  { double us = time_us([&] { hipLaunchKernelGGL((k_gather<0, 8>), dim3(4096), dim3(256), 0, 0, dTi, dxm, dout, nnz, 0x7fffffff); });
+    printf("gather 1e7 x 8B from 16 MB (full m) table: %.1f us (%.1f Ggather/s)\n", us, nnz / us / 1e3); }
+
+  for (int mask : {(1 << 17) - 1, (1 << 20) - 1, 0x7fffffff}) {
+    double t[5];
+    t[0] = time_us([&] { hipLaunchKernelGGL((k_gather_pol<0>), dim3(8192), dim3(256), 0, 0, dTi, dxm, dout, nnz, mask); });
+    t[1] = time_us([&] { hipLaunchKernelGGL((k_gather_pol<1>), dim3(8192), dim3(256), 0, 0, dTi, dxm, dout, nnz, mask); });
+    t[2] = time_us([&] { hipLaunchKernelGGL((k_gather_pol<2>), dim3(8192), dim3(256), 0, 0, dTi, dxm, dout, nnz, mask); });
+    t[3] = time_us([&] { hipLaunchKernelGGL((k_gather_pol<3>), dim3(8192), dim3(256), 0, 0, dTi, dxm, dout, nnz, mask); });
+    t[4] = time_us([&] { hipLaunchKernelGGL((k_gather_pol<4>), dim3(8192), dim3(256), 0, 0, dTi, dxm, dout, nnz, mask); });
+    printf("gather policy (mask %x) [1 load in flight/lane]: plain %.1f  nt %.1f  sc1 %.1f  sc0sc1 %.1f  nt-asm %.1f us\n", mask, t[0], t[1], t[2], t[3], t[4]);
+  }
+  // (2c) column-sliced passes: S sub-matrices of CSR(A) by column range, y += A_s x_s per pass
+  for (int S : {2, 4, 8}) {
+    std::vector<std::vector<int>> sp(S, std::vector<int>(m + 1, 0)), si(S);
+    std::vector<std::vector<double>> sx(S);
+    for (int r = 0; r < m; ++r) {
+      for (int k = Ap[r]; k < Ap[r + 1]; ++k) { int sl = (int)((long long)Ai[k] * S / n); si[sl].push_back(Ai[k]); sx[sl].push_back(Ax[k]); }
+      for (int t = 0; t < S; ++t) sp[t][r + 1] = (int)si[t].size();
+    }
+    std::vector<Csr> mats; std::vector<int> grids;
+    for (int t = 0; t < S; ++t) { std::vector<int> rb; build_rowblk(m, sp[t], 2048, 2048, rb);
+      Csr A{m, n, (int)rb.size() - 1, dev(sp[t]), dev(si[t]), dev(rb), dev(sx[t])}; mats.push_back(A); grids.push_back(std::min(A.nblk, 16384)); }
+    double us = time_us([&] { for (int t = 0; t < S; ++t) hipLaunchKernelGGL((k_csr_stream<2048, 256, 8>), dim3(grids[t]), dim3(256), 0, 0, mats[t], dxm, dy); });
+    printf("A column-sliced S=%d passes (y += A_s x_s): %.1f us total\n", S, us);
+  }
+  // (3) csr_stream variants
+  auto run = [&](const char *name, int rows, int cols, int *p, int *i, double *v, double *x, long long bytes) {
+    std::vector<int> hp(rows + 1); CK(hipMemcpy(hp.data(), p, (rows + 1) * 4, hipMemcpyDeviceToHost));
+    for (int nnzb : {1024, 2048, 4096}) {
+      std::vector<int> rb; build_rowblk(rows, hp, nnzb, 2048, rb); int *drb = dev(rb);
+      Csr A{rows, cols, (int)rb.size() - 1, p, i, drb, v};
+      int g = std::min(A.nblk, 16384);
+#define RUN(NB, BL, FL, label) if (nnzb == NB) { double us = time_us([&] { hipLaunchKernelGGL((k_csr_stream<NB, BL, FL>), dim3(g), dim3(BL), 0, 0, A, x, dy); }); \
+        printf("%s nnzb=%d block=%d %-22s: %7.1f us  %6.0f GB/s\n", name, NB, BL, label, us, bytes / us / 1e3); }
+      RUN(1024, 256, 0, "base") RUN(1024, 256, 1, "nt") RUN(1024, 128, 1, "nt")
+      RUN(2048, 256, 0, "base") RUN(2048, 256, 1, "nt") RUN(2048, 256, 2, "no-gather") RUN(2048, 256, 3, "nt no-gather") RUN(2048, 256, 5, "nt no-phase2") RUN(2048, 256, 7, "nt no-gather no-ph2")
+      RUN(2048, 512, 1, "nt") RUN(4096, 256, 1, "nt") RUN(4096, 512, 1, "nt") RUN(4096, 1024, 1, "nt")
+      CK(hipFree(drb));
+    }
+    Csr A{rows, cols, 0, p, i, nullptr, v};
+    double us = time_us([&] { hipLaunchKernelGGL(k_csr_scalar, dim3(8192), dim3(256), 0, 0, A, x, dy); });
+    printf("%s scalar row-per-lane            : %7.1f us  %6.0f GB/s\n", name, us, bytes / us / 1e3);
+  };
+  long long bA = (long long)nnz * 12 + (m + 1) * 4LL + n * 8LL + m * 8LL, bT = (long long)nnz * 12 + (n + 1) * 4LL + m * 8LL + n * 8LL;
+  run("A  (m rows, gather n)", m, n, dAp, dAi, dAx, dxm, bA);
+  run("At (n rows, gather m)", n, m, dTp, dTi, dTx, dxm, bT);
+  return 0;
+}

@@ -280,7 +280,7 @@ def info_dict(info):
     return d
 
 
-def solve(lib, prob, settings=None, warm=None, want_stats=False, profiling=False, **over):
+def solve(lib, prob, settings=None, warm=None, want_stats=False, profiling=False, cg_tol_override=None, **over):
     """scs_init -> scs_solve -> scs_finish through the C ABI of `lib`.
     Returns dict(x, y, s, info[, stats])."""
     T = lib._scs_types
@@ -299,6 +299,8 @@ def solve(lib, prob, settings=None, warm=None, want_stats=False, profiling=False
     try:
         if profiling and hasattr(lib, "scs_amd_set_profiling"):
             lib.scs_amd_set_profiling(w, 1)
+        if cg_tol_override is not None:
+            lib.scs_amd_set_cg_tol_override(w, float(cg_tol_override))  # test hook (HIP library only)
         lib.scs_solve(w, C.byref(sol), C.byref(info), 1 if warm is not None else 0)
         out = dict(x=x, y=y, s=s, info=info_dict(info))
         if want_stats and hasattr(lib, "scs_amd_get_stats"):

@@ -32,9 +32,21 @@ def test_linsys_boundary_vectors():
         want = g[f"xy{c}"]
         rc = lib.scs_solve_lin_sys(w, b.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp) if len(s) else None, tol)
         assert rc == 0
-        # same algorithm, same stopping rule: identical CG path up to summation order
+        rhs = np.array(g[f"b{c}"])
+        x, y = b[:n], b[n:]
+        rx, ry = dr[:n], dr[n:]
+        # stopping rule of private.c:202: reduced residual below tol in the inf-norm
+        red = rx * x + A.T @ ((A @ x) / ry) - (rhs[:n] + A.T @ (rhs[n:] / ry))
+        assert np.abs(red).max() < max(tol, 1e-12) * (1 + 1e-9) + 1e-13 * np.abs(rhs).max(), (int(c), tol)
+        assert np.abs((A @ x - rhs[n:]) / ry - y).max() <= 1e-12 * max(1.0, np.abs(y).max())
         err = np.abs(b - want).max() / max(np.abs(want).max(), 1e-300)
-        assert err <= 1e-9, (int(c), tol, err)
+        if tol <= 1e-9:
+            # tight solves pin the answer itself
+            assert err <= 1e-9, (int(c), tol, err)
+        else:
+            # loose solves: CG iterates depend on summation order to O(tol) -- the
+            # reference's own answer is only one of many that meet its stopping rule
+            assert err <= 50 * tol, (int(c), tol, err)
     lib.scs_free_lin_sys_work(w)
 
 
