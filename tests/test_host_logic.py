@@ -1,0 +1,99 @@
+"""Host-side logic on CPU: generators, batching over gloo (world_size 2)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from scs_amd import batch, capi, problems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generator_is_feasible_and_complementary():
+    cone = dict(z=5, l=9, bl=[-1.0, -2.0], bu=[0.5, 1.0], q=[1, 2, 7, 30], s=[1, 3, 6])
+    m = capi.cone_rows(cone)
+    pr = problems.random_cone_prob(25, m, 4, cone, seed=3)
+    y, s = pr["y_opt"], pr["s_opt"]
+    assert abs(y @ s) <= 1e-9 * max(1.0, np.abs(y).max() * np.abs(s).max())   # s'y = 0
+    assert np.abs(problems.proj_dual_cone_np(y, cone) - y).max() <= 1e-9       # y in K*
+    assert np.abs(problems.proj_dual_cone_np(-s, cone)).max() <= 1e-9          # s in K  (Moreau)
+    A = pr["A"]
+    assert np.abs(A @ pr["x_opt"] + s - pr["b"]).max() <= 1e-12 * max(1, np.abs(pr["b"]).max())
+    assert np.abs(A.T @ y + pr["c"]).max() <= 1e-12 * max(1, np.abs(pr["c"]).max())
+    assert np.all(np.diff(A.indptr) == 4)
+    for j in range(A.shape[1]):
+        r = A.indices[A.indptr[j]:A.indptr[j + 1]]
+        assert np.all(np.diff(r) > 0)
+
+
+def test_socp_cone_recipe_matches_reference_law():
+    c = problems.socp_cone_sizes(4000)   # test/random_socp_prob.c:79-107 with m = 4000
+    assert c["z"] == 400 and c["l"] == 1200
+    assert sum(c["q"]) == 4000 - 1600
+    import math
+    assert max(c["q"]) <= math.ceil(4000 / math.log(4000))
+    c2 = problems.socp_cone_sizes(1000, q_fixed=8)
+    assert set(c2["q"][:-1]) == {8}
+
+
+def test_partition_is_a_partition():
+    for count, world in ((64, 8), (7, 2), (3, 4), (0, 2)):
+        seen = sorted(i for r in range(world) for i in batch.partition(count, world, r))
+        assert seen == list(range(count))
+        sizes = [len(batch.partition(count, world, r)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_batch_roundtrip():
+    def solve_one(j, d):
+        return dict(status_val=1, iter=25 * j, pobj=float(j), dobj=float(j), res_pri=0.0, res_dual=0.0, gap=0.0)
+    tab = batch.run_batch(dict(n=10, m=20, col_nnz=2, seed=1, count=5, aa=0, max_iters=10), solve_one)
+    assert tab.shape == (5, len(batch.REC_FIELDS))
+    assert list(tab[:, 0]) == [0, 1, 2, 3, 4] and list(tab[:, 2]) == [0, 25, 50, 75, 100]
+
+
+def test_two_rank_gloo_batch_matches_serial():
+    """world_size 2 over gloo on CPU: descriptor broadcast + record all-gather; the solves are
+    the oracle restatement (checker used as a stand-in solver in this CPU test only)."""
+    script = textwrap.dedent('''
+        import os, sys, json
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        from scs_amd import batch, capi, problems
+        from oracle import pyoracle
+        dist.init_process_group(backend="gloo")
+        def solve_one(j, d):
+            pr = problems.random_socp(d["n"], d["m"], d["col_nnz"], seed=d["seed"] + j)
+            prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+            return pyoracle.oracle_solve(prob, max_iters=d["max_iters"])["info"]
+        desc = dict(n=40, m=120, col_nnz=4, seed=100, count=5, aa=0, max_iters=400) if dist.get_rank() == 0 else {}
+        tab = batch.run_batch(desc, solve_one, dist=dist, device="cpu")
+        if dist.get_rank() == 0:
+            print("TABLE " + json.dumps(tab.tolist()))
+        dist.barrier()
+        dist.destroy_process_group()
+    ''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    # torch.distributed.run needs a file: write one
+    import tempfile, json
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(script)
+        path = f.name
+    try:
+        out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                       "--master-addr", "127.0.0.1", "--master-port", "29611", path], env=env, text=True,
+                                      stderr=subprocess.STDOUT, timeout=600)
+    finally:
+        os.unlink(path)
+    line = [l for l in out.splitlines() if l.startswith("TABLE ")][0]
+    tab = np.array(json.loads(line[6:]))
+    assert tab.shape == (5, len(batch.REC_FIELDS))
+    from oracle import pyoracle
+    for j in range(5):
+        pr = problems.random_socp(40, 120, 4, seed=100 + j)
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+        info = pyoracle.oracle_solve(prob, max_iters=400)["info"]
+        assert int(tab[j, 0]) == j and int(tab[j, 2]) == info["iter"]
+        assert abs(tab[j, 3] - info["pobj"]) <= 1e-12 * max(1, abs(info["pobj"]))
