@@ -261,6 +261,18 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
 /* test hook: every per-iteration linear solve uses this tolerance instead of the
  * schedule of src/scs.c:745-762 (0 restores the schedule) */
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
+/* Host-side Anderson acceleration, as used inside scs_solve; same contract as the
+ * reference's aa_init / aa_apply / aa_safeguard / aa_reset / aa_finish
+ * (include/aa.h:66-143).  Pure host code (exposed so it can be tested without a GPU). */
+void *scs_amd_aa_init(scs_int dim, scs_int mem, scs_int min_len, scs_int type1,
+                      scs_float regularization, scs_float relaxation,
+                      scs_float safeguard_factor, scs_float max_weight_norm,
+                      scs_int ir_max_steps);
+scs_float scs_amd_aa_apply(scs_float *f, const scs_float *x, void *a);
+scs_int scs_amd_aa_safeguard(scs_float *f_new, scs_float *x_new, void *a);
+void scs_amd_aa_reset(void *a);
+void scs_amd_aa_finish(void *a);
+void scs_amd_aa_get_stats(const void *a, AaStats *out);
 /* number of visible HIP devices, or <0 with no usable runtime (never throws) */
 scs_int scs_amd_device_count(void);
 /* select the device used by subsequently created workspaces (default 0) */

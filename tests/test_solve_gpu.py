@@ -157,3 +157,41 @@ def test_stepping_api_equals_scs_solve():
     amd.scs_finish(w)
     assert info.iter == r1["info"]["iter"]
     assert np.array_equal(x, r1["x"])  # deterministic reductions: bit-identical reruns
+
+
+def test_anderson_acceleration_on_matches_reference():
+    """Default settings (AA type-I, lookback 10).  Host AA is pinned against src/aa.c in
+    tests/test_aa_host.py; here the whole accelerated solve, exact CG on both sides."""
+    ref = _ref("libscsindir_ref_exactcg.so")
+    amd = capi.load("libscsamd.so")
+    pr = problems.random_socp(600, 1800, 12, seed=21)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    kw = dict(verbose=0, eps_abs=1e-8, eps_rel=1e-8)  # long enough for the AA memory to fill (10 x 10 its)
+    ra = capi.solve(amd, prob, cg_tol_override=1e-12, **kw)
+    rr = capi.solve(ref, prob, **kw)
+    ia, ir = ra["info"], rr["info"]
+    assert ia["status_val"] == ir["status_val"] == 1
+    assert ir["accepted_accel_steps"] > 0 and ia["accepted_accel_steps"] > 0
+    assert abs(ia["accepted_accel_steps"] - ir["accepted_accel_steps"]) <= 3
+    # AA's least-squares solve amplifies rounding differences: allow a different
+    # termination check, but the optimum must agree
+    assert abs(ia["iter"] - ir["iter"]) <= 50, (ia["iter"], ir["iter"])
+    scale = max(1.0, abs(ir["pobj"]))
+    assert abs(ia["pobj"] - ir["pobj"]) <= 5e-4 * scale
+    # AA pays off on both sides vs. the un-accelerated run
+    r0 = capi.solve(amd, prob, acceleration_lookback=0, cg_tol_override=1e-12, **kw)
+    assert ia["iter"] <= r0["info"]["iter"]
+
+
+def test_sdp_with_box_exact_cg_parity():
+    ref = _ref("libscsindir_ref_exactcg.so")
+    amd = capi.load("libscsamd.so")
+    pr = problems.random_sdp(150, n_blocks=12, block=10, bsize=41, col_nnz=6, seed=5)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    kw = dict(verbose=0, acceleration_lookback=0)
+    ra, rr = capi.solve(amd, prob, cg_tol_override=1e-12, **kw), capi.solve(ref, prob, **kw)
+    ia, ir = ra["info"], rr["info"]
+    assert ia["status_val"] == ir["status_val"] == 1
+    assert ia["iter"] == ir["iter"]
+    for k in ("pobj", "dobj", "res_pri", "res_dual", "gap"):
+        assert _rel(ia[k], ir[k], floor=1e-3) <= REL, (k, ia[k], ir[k])
