@@ -122,6 +122,118 @@ __global__ __launch_bounds__(256) void k_csr_scalar(Csr A, const double *__restr
   }
 }
 
+
+// ---- (4) column-sliced, time-aligned SpMV ("all workgroups walk the slices of x together") ----
+struct Sliced { int rows, nsb, S, SB; const int *sbrow; const int *segoff; const unsigned *sidx; const double *sval; };
+template <int CH> __global__ __launch_bounds__(256) void k_sliced(Sliced A, const double *__restrict__ x, double *y, int accrows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *acc = reinterpret_cast<double *>(smem);
+  double *sp = acc + accrows;
+  unsigned short *sr = reinterpret_cast<unsigned short *>(sp + CH);
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int r0 = A.sbrow[b], nr = A.sbrow[b + 1] - r0;
+  for (int r = tid; r < nr; r += 256) acc[r] = 0;
+  __syncthreads();
+  const unsigned mask = (1u << A.SB) - 1;
+  for (int s = 0; s < A.S; ++s) {
+    const int e0 = A.segoff[b * (A.S + 1) + s], e1 = A.segoff[b * (A.S + 1) + s + 1];
+    const double *xs = x + ((size_t)s << A.SB);
+    for (int base = e0; base < e1; base += CH) {
+      const int cnt = min(CH, e1 - base);
+      unsigned w[CH / 256]; double v[CH / 256];
+#pragma unroll
+      for (int j = 0; j < CH / 256; ++j) { const int k = tid + j * 256; const bool ok = k < cnt; w[j] = ok ? A.sidx[base + k] : 0u; v[j] = ok ? A.sval[base + k] : 0.0; }
+      double xx[CH / 256];
+#pragma unroll
+      for (int j = 0; j < CH / 256; ++j) xx[j] = xs[w[j] & mask];
+#pragma unroll
+      for (int j = 0; j < CH / 256; ++j) { const int k = tid + j * 256; if (k < cnt) { sp[k] = v[j] * xx[j]; sr[k] = (unsigned short)(w[j] >> A.SB); } }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < CH / 256; ++j) { const int k = tid + j * 256;
+        if (k < cnt) { const unsigned short lr = sr[k];
+          if (k == 0 || sr[k - 1] != lr) { double sum = sp[k]; int kk = k + 1; while (kk < cnt && sr[kk] == lr) sum += sp[kk++]; acc[lr] += sum; } } }
+      __syncthreads();
+    }
+  }
+  for (int r = tid; r < nr; r += 256) y[r0 + r] = acc[r];
+}
+
+
+// pipelined variant: the next chunk's idx/val loads are in flight while the current chunk is reduced
+template <int CH> __global__ __launch_bounds__(256) void k_sliced_pf(Sliced A, const double *__restrict__ x, double *y, int accrows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *acc = reinterpret_cast<double *>(smem);
+  double *sp = acc + accrows;
+  unsigned short *sr = reinterpret_cast<unsigned short *>(sp + CH);
+  constexpr int U = CH / 256;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int r0 = A.sbrow[b], nr = A.sbrow[b + 1] - r0;
+  for (int r = tid; r < nr; r += 256) acc[r] = 0;
+  const unsigned mask = (1u << A.SB) - 1;
+  const int *so = A.segoff + (size_t)b * (A.S + 1);
+  const int eend = so[A.S];
+  // chunk cursor: [base, base+cnt) inside slice s
+  int s = 0, base = so[0];
+  while (s < A.S && base >= so[s + 1]) ++s;
+  unsigned w[U]; double v[U];
+  int cnt = 0;
+  if (s < A.S) { cnt = min(CH, so[s + 1] - base);
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int k = tid + j * 256; const bool ok = k < cnt; w[j] = ok ? A.sidx[base + k] : 0u; v[j] = ok ? A.sval[base + k] : 0.0; } }
+  __syncthreads();
+  while (s < A.S) {
+    const double *xs = x + ((size_t)s << A.SB);
+    double xx[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) xx[j] = xs[w[j] & mask];
+    // cursor of the next chunk + its loads (prefetch)
+    int s2 = s, base2 = base + cnt;
+    while (s2 < A.S && base2 >= so[s2 + 1]) ++s2;
+    unsigned w2[U]; double v2[U]; int cnt2 = 0;
+    if (s2 < A.S) { cnt2 = min(CH, so[s2 + 1] - base2);
+#pragma unroll
+      for (int j = 0; j < U; ++j) { const int k = tid + j * 256; const bool ok = k < cnt2; w2[j] = ok ? A.sidx[base2 + k] : 0u; v2[j] = ok ? A.sval[base2 + k] : 0.0; } }
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int k = tid + j * 256; if (k < cnt) { sp[k] = v[j] * xx[j]; sr[k] = (unsigned short)(w[j] >> A.SB); } }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int k = tid + j * 256;
+      if (k < cnt) { const unsigned short lr = sr[k];
+        if (k == 0 || sr[k - 1] != lr) { double sum = sp[k]; int kk = k + 1; while (kk < cnt && sr[kk] == lr) sum += sp[kk++]; acc[lr] += sum; } } }
+    __syncthreads();
+    s = s2; base = base2; cnt = cnt2;
+#pragma unroll
+    for (int j = 0; j < U; ++j) { w[j] = w2[j]; v[j] = v2[j]; }
+  }
+  (void)eend;
+  for (int r = tid; r < nr; r += 256) y[r0 + r] = acc[r];
+}
+
+static int g_maxrows = 0;
+static Sliced build_sliced(int rows, int cols, const std::vector<int> &ptr, const std::vector<int> &idx, const std::vector<double> &val, int SB, int nnz_sb) {
+  int S = (cols + (1 << SB) - 1) >> SB;
+  std::vector<int> sbrow; sbrow.push_back(0);
+  int r = 0;
+  while (r < rows) { int s0 = r; long long acc = 0; while (r < rows && r - s0 < 4096) { long long rn = ptr[r + 1] - ptr[r]; if (acc + rn > nnz_sb && r > s0) break; acc += rn; ++r; } sbrow.push_back(r); }
+  int nsb = (int)sbrow.size() - 1;
+  g_maxrows = 0; for (int b = 0; b < nsb; ++b) g_maxrows = std::max(g_maxrows, sbrow[b + 1] - sbrow[b]);
+  size_t nnz = idx.size();
+  std::vector<unsigned> sidx(nnz); std::vector<double> sval(nnz); std::vector<int> segoff((size_t)nsb * (S + 1));
+  for (int b = 0; b < nsb; ++b) {
+    int k0 = ptr[sbrow[b]], k1 = ptr[sbrow[b + 1]];
+    std::vector<int> cnt(S + 1, 0);
+    for (int k = k0; k < k1; ++k) cnt[(idx[k] >> SB) + 1]++;
+    for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
+    for (int s = 0; s <= S; ++s) segoff[(size_t)b * (S + 1) + s] = k0 + cnt[s];
+    std::vector<int> nx(cnt.begin(), cnt.end() - 1);
+    for (int rr = sbrow[b]; rr < sbrow[b + 1]; ++rr) for (int k = ptr[rr]; k < ptr[rr + 1]; ++k) {
+      int s = idx[k] >> SB; int q = k0 + nx[s]++; sidx[q] = (unsigned)(idx[k] & ((1 << SB) - 1)) | ((unsigned)(rr - sbrow[b]) << SB); sval[q] = val[k]; }
+  }
+  Sliced A{rows, nsb, S, SB, dev(sbrow), dev(segoff), dev(sidx), dev(sval)};
+  return A;
+}
+
 static void build_rowblk(int rows, const std::vector<int> &ptr, int nnzb, int rowsmax, std::vector<int> &rb) {
   rb.clear(); rb.push_back(0); int r = 0;
   while (r < rows) { int s = r; long long acc = 0;
@@ -152,7 +264,8 @@ int main(int argc, char **argv) {
   double *dTx = dev(Tx), *dAx = dev(Ax), *dxm = dev(hx), *dy = devz<double>(m), *dout = devz<double>(16);
 
   // (1) copy
-  { size_t n2 = nnz / 2; double us = time_us([&] { hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, 0, (const double2 *)dTx, (double2 *)dy == nullptr ? nullptr : (double2 *)dAx, n2); });
+  double *dcopy = devz<double>(nnz);
+  { size_t n2 = nnz / 2; double us = time_us([&] { hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, 0, (const double2 *)dTx, (double2 *)dcopy, n2); });
     printf("copy 2x%.0f MB: %.1f us  %.0f GB/s\n", nnz * 8 / 1e6, us, 2.0 * nnz * 8 / us / 1e3); }
   { double us = time_us([&] { hipLaunchKernelGGL((k_stream<0>), dim3(4096), dim3(256), 0, 0, dTx, dTi, dout, nnz); });
     printf("stream val+idx (120 MB): %.1f us  %.0f GB/s\n", us, nnz * 12.0 / us / 1e3);
@@ -188,6 +301,38 @@ int main(int argc, char **argv) {
       Csr A{m, n, (int)rb.size() - 1, dev(sp[t]), dev(si[t]), dev(rb), dev(sx[t])}; mats.push_back(A); grids.push_back(std::min(A.nblk, 16384)); }
     double us = time_us([&] { for (int t = 0; t < S; ++t) hipLaunchKernelGGL((k_csr_stream<2048, 256, 8>), dim3(grids[t]), dim3(256), 0, 0, mats[t], dxm, dy); });
     printf("A column-sliced S=%d passes (y += A_s x_s): %.1f us total\n", S, us);
+  }
+
+  // (4) sliced kernels, correctness vs scalar kernel + timing
+  {
+    double *dref = devz<double>(m), *dys = devz<double>(m);
+    auto check = [&](const char *name, int rows, int cols, const std::vector<int> &P, const std::vector<int> &I, const std::vector<double> &V, int *dp, int *di, double *dv, long long bytes) {
+      Csr C{rows, cols, 0, dp, di, nullptr, dv};
+      hipLaunchKernelGGL(k_csr_scalar, dim3(8192), dim3(256), 0, 0, C, dxm, dref);
+      for (int SB : {16, 17, 18}) for (int nnz_sb : {8192, 12288, 16384}) {
+        Sliced A = build_sliced(rows, cols, P, I, V, SB, nnz_sb);
+        int ar = (g_maxrows + 1) & ~1;
+        size_t l2 = (size_t)ar * 8 + 2048 * 10, l1 = (size_t)ar * 8 + 1024 * 10, l0 = (size_t)ar * 8 + 512 * 10;
+        CK(hipMemset(dys, 0, rows * 8));
+        hipLaunchKernelGGL((k_sliced<2048>), dim3(A.nsb), dim3(256), l2, 0, A, dxm, dys, ar);
+        std::vector<double> h1(rows), h2(rows); CK(hipMemcpy(h1.data(), dref, rows * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dys, rows * 8, hipMemcpyDeviceToHost));
+        double err = 0; for (int i = 0; i < rows; ++i) err = std::max(err, fabs(h1[i] - h2[i]));
+        double us = time_us([&] { hipLaunchKernelGGL((k_sliced<2048>), dim3(A.nsb), dim3(256), l2, 0, A, dxm, dys, ar); });
+        double us1 = time_us([&] { hipLaunchKernelGGL((k_sliced<1024>), dim3(A.nsb), dim3(256), l1, 0, A, dxm, dys, ar); });
+        double us0 = time_us([&] { hipLaunchKernelGGL((k_sliced<512>), dim3(A.nsb), dim3(256), l0, 0, A, dxm, dys, ar); });
+        double p2 = time_us([&] { hipLaunchKernelGGL((k_sliced_pf<2048>), dim3(A.nsb), dim3(256), l2, 0, A, dxm, dys, ar); });
+        double p1 = time_us([&] { hipLaunchKernelGGL((k_sliced_pf<1024>), dim3(A.nsb), dim3(256), l1, 0, A, dxm, dys, ar); });
+        double p0 = time_us([&] { hipLaunchKernelGGL((k_sliced_pf<512>), dim3(A.nsb), dim3(256), l0, 0, A, dxm, dys, ar); });
+        CK(hipMemset(dys, 0, rows * 8));
+        hipLaunchKernelGGL((k_sliced_pf<1024>), dim3(A.nsb), dim3(256), l1, 0, A, dxm, dys, ar);
+        { std::vector<double> h3(rows); CK(hipMemcpy(h3.data(), dys, rows * 8, hipMemcpyDeviceToHost)); double e3 = 0; for (int i = 0; i < rows; ++i) e3 = std::max(e3, fabs(h1[i] - h3[i])); printf("   PF: CH2048 %.1f | CH1024 %.1f | CH512 %.1f us  err %.1e\n", p2, p1, p0, e3); }
+        printf("%s sliced SB=%d (S=%d) nnz_sb=%d nsb=%d maxrows=%d: CH2048 %.1f us | CH1024 %.1f us | CH512 %.1f us (%.0f GB/s best) maxerr %.2e\n", name, SB, A.S, nnz_sb, A.nsb, g_maxrows, us, us1, us0, bytes / std::min(us, std::min(us1, us0)) / 1e3, err);
+        CK(hipFree((void*)A.sbrow)); CK(hipFree((void*)A.segoff)); CK(hipFree((void*)A.sidx)); CK(hipFree((void*)A.sval));
+      }
+    };
+    long long bA2 = (long long)nnz * 12 + (m + 1) * 4LL + n * 8LL + m * 8LL, bT2 = (long long)nnz * 12 + (n + 1) * 4LL + m * 8LL + n * 8LL;
+    check("A ", m, n, Ap, Ai, Ax, dAp, dAi, dAx, bA2);
+    check("At", n, m, Tp, Ti, Tx, dTp, dTi, dTx, bT2);
   }
   // (3) csr_stream variants
   auto run = [&](const char *name, int rows, int cols, int *p, int *i, double *v, double *x, long long bytes) {

@@ -4,6 +4,7 @@
 // every vector in HBM and the loop controlled from the device.
 #pragma once
 #include "spmv.h"
+#include "spmv_sliced.h"
 
 namespace scsamd {
 

@@ -21,7 +21,9 @@
 namespace scsamd {
 
 constexpr int VEC_MAX_GRID = 2048;
-constexpr int PART_CAP = 4096; // >= SPMV_MAX_GRID and >= VEC_MAX_GRID
+constexpr int PART_CAP = SL_MAX_GRID; // >= SPMV_MAX_GRID, >= SL_MAX_GRID and >= 2 * VEC_MAX_GRID
+
+CsrDev::~CsrDev() { delete sliced; }
 
 static inline int vec_grid(long long len) {
   static const int cap = [] {
@@ -219,10 +221,27 @@ LinSys::~LinSys() {
 
 void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, const EpiArgs &e,
                          const int *skip) {
-  const int g = mat.grid();
   int slot = -1;
   const bool sample = profiling && ((spmv_sample_ctr++ & 7) == 0);
   if (sample) slot = spmv_timer.start(stream);
+  if (mat.sliced && mat.sliced->built) {
+    const SlicedDev &sd = *mat.sliced;
+    const int g = sd.grid();
+    const size_t lds = sd.lds_bytes();
+    SlicedView v = sd.view();
+    switch (epi) {
+    case EPI_PLAIN: hipLaunchKernelGGL(csr_sliced_kernel<EPI_PLAIN>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
+    case EPI_DIV: hipLaunchKernelGGL(csr_sliced_kernel<EPI_DIV>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
+    case EPI_GP: hipLaunchKernelGGL(csr_sliced_kernel<EPI_GP>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
+    case EPI_ACC: hipLaunchKernelGGL(csr_sliced_kernel<EPI_ACC>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
+    case EPI_NEGDIV: hipLaunchKernelGGL(csr_sliced_kernel<EPI_NEGDIV>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
+    default: throw HipError("scs_amd: bad spmv epilogue");
+    }
+    if (sample) spmv_timer.stop(slot, stream);
+    n_spmv++;
+    return;
+  }
+  const int g = mat.grid();
   CsrView v = mat.view();
   switch (epi) {
   case EPI_PLAIN: hipLaunchKernelGGL(csr_stream_kernel<EPI_PLAIN>, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, v, x, y, e, skip); break;
@@ -268,11 +287,19 @@ void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s)
   }
   // CSC(A) is CSR(A'): upload as is
   At.upload(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+  if (SlicedDev::wanted(m, A_csc->p, n)) {
+    At.sliced = new SlicedDev();
+    At.sliced->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+  }
   {
     std::vector<int> Cp, Ci;
     std::vector<real> Cx;
     host_transpose(m, n, A_csc->p, A_csc->i, A_csc->x, Cp, Ci, Cx);
     A.upload(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
+    if (SlicedDev::wanted(n, Cp.data(), m)) {
+      A.sliced = new SlicedDev();
+      A.sliced->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
+    }
   }
   has_P = P_csc != nullptr;
   if (has_P) {
@@ -411,7 +438,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
   const long long max_its = 10LL * n; // private.c:307
   long long it = 0;
   int batch = std::max(4, std::min(last_its + 1, 4096));
-  const int gAt = At.grid();
+  const int gAt = (At.sliced && At.sliced->built) ? At.sliced->grid() : At.grid();
   // partial arrays: partA <- p'Gp (K2), partB <- z'r and partB+PART_CAP/2 <- |r| (K3)
   real *part_pgp = partA.p, *part_ztr = partB.p, *part_max = partB.p + PART_CAP / 2;
   for (;;) {

@@ -136,7 +136,12 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, con
 #endif // __HIPCC__
 
 // ---- device-resident CSR with its row-block table ---------------------------
+struct SlicedDev;
 struct CsrDev {
+  SlicedDev *sliced = nullptr; // owned; built by LinSys::init when SlicedDev::wanted()
+  ~CsrDev();
+  CsrDev() = default;
+  CsrDev(const CsrDev &) = delete;
   int rows = 0, cols = 0, nblk = 0;
   long long nnz = 0;
   DevBuf<int> ptr, idx, rowblk;

@@ -1,0 +1,192 @@
+// spmv_sliced.h -- column-sliced, time-aligned CSR product for gather vectors that do
+// not fit a 4 MB XCD L2 (same results and epilogues as csr_stream_kernel in spmv.h).
+//
+// Why: on the headline config the product is gather-bound, not stream-bound.  Measured
+// on MI355X (lab/spmv_lab.hip, 1e7 random 8-byte gathers): 37 us when the table is
+// L2-resident (<= 4 MB), 80 us at 8 MB, 111 us at 16 MB, against 17 us to stream the
+// 120 MB of val/idx.  The vectors gathered here are 8 MB (p) and 16 MB (R_y^-1 A p).
+//
+// How: a workgroup owns a "super-block" of consecutive rows holding ~8192 nonzeros and
+// keeps one accumulator per row in LDS.  Inside the super-block the entries are stored
+// sorted by (column slice, row), a slice being 2^16 consecutive columns (512 KB of fp64
+// x).  Every workgroup walks the slices in the same order starting at the same time, so
+// at any moment the workgroups sharing an XCD gather from the same one or two slices of
+// x -- L2-resident -- without any barrier between workgroups.  Per entry the format
+// stores val (8 B) and one packed word (4 B): column-within-slice | local row << 16, i.e.
+// the same 12 B/nnz as CSR and no row-pointer array.  A chunk of products goes to LDS;
+// the first lane of each (row, slice) run adds the run to its row accumulator (runs are
+// contiguous because of the sort, so no two lanes touch the same accumulator:
+// deterministic, no atomics).  Summation order inside a row is slice-major instead of
+// the reference's index order (rounding-level difference only).
+// Measured: 62-65 us per product in either orientation vs 111/150 us for csr_stream.
+#pragma once
+#include "spmv.h"
+#include <algorithm>
+
+namespace scsamd {
+
+constexpr int SL_SLICE_BITS = 16;  // columns per slice = 65536
+constexpr int SL_NNZ_SB = 8192;    // nonzeros per super-block (target)
+constexpr int SL_ROWS_MAX = 4096;  // rows per super-block (LDS accumulators)
+constexpr int SL_CHUNK = 512;      // products staged per step
+constexpr int SL_MAX_GRID = 16384;
+
+struct SlicedView {
+  int rows, nsb, S;
+  const int *sbrow;       // nsb + 1 : first row of each super-block
+  const int *segoff;      // nsb * (S + 1) : start of each (super-block, slice) run
+  const unsigned *sidx;   // nnz : (col & 0xffff) | local_row << 16
+  const real *sval;       // nnz
+};
+
+#ifdef __HIPCC__
+template <int EPI>
+__global__ __launch_bounds__(SCSAMD_BLOCK) void csr_sliced_kernel(SlicedView A, const real *__restrict__ x, real *y,
+                                                                  EpiArgs e, const int *skip, int accrows) {
+  if (skip && *skip) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sl_smem[];
+  real *acc = reinterpret_cast<real *>(sl_smem);
+  real *sp = acc + accrows;
+  unsigned short *sr = reinterpret_cast<unsigned short *>(sp + SL_CHUNK);
+  real *red = reinterpret_cast<real *>(sr + SL_CHUNK); // 8-byte aligned: SL_CHUNK * 2 B is a multiple of 8
+  constexpr int U = SL_CHUNK / SCSAMD_BLOCK;
+  const int tid = threadIdx.x;
+  const unsigned mask = (1u << SL_SLICE_BITS) - 1;
+  real dot = 0;
+  for (int b = blockIdx.x; b < A.nsb; b += gridDim.x) {
+    const int r0 = A.sbrow[b], nr = A.sbrow[b + 1] - r0;
+    for (int r = tid; r < nr; r += SCSAMD_BLOCK) acc[r] = 0;
+    __syncthreads();
+    const int *so = A.segoff + (size_t)b * (A.S + 1);
+    for (int s = 0; s < A.S; ++s) {
+      const int e0 = so[s], e1 = so[s + 1];
+      const real *xs = x + ((size_t)s << SL_SLICE_BITS);
+      for (int base = e0; base < e1; base += SL_CHUNK) {
+        const int cnt = min(SL_CHUNK, e1 - base);
+        unsigned w[U];
+        real v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int k = tid + j * SCSAMD_BLOCK;
+          const bool ok = k < cnt;
+          w[j] = ok ? A.sidx[base + k] : 0u;
+          v[j] = ok ? A.sval[base + k] : (real)0;
+        }
+        real xx[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) xx[j] = xs[w[j] & mask];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int k = tid + j * SCSAMD_BLOCK;
+          if (k < cnt) {
+            sp[k] = v[j] * xx[j];
+            sr[k] = (unsigned short)(w[j] >> SL_SLICE_BITS);
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int k = tid + j * SCSAMD_BLOCK;
+          if (k < cnt) {
+            const unsigned short lr = sr[k];
+            if (k == 0 || sr[k - 1] != lr) { // first lane of a (row, slice) run owns it
+              real sum = sp[k];
+              int kk = k + 1;
+              while (kk < cnt && sr[kk] == lr) sum += sp[kk++];
+              acc[lr] += sum;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int r = tid; r < nr; r += SCSAMD_BLOCK) {
+      const real a = epi_init<EPI>(e, y, r0 + r) + acc[r];
+      epi_apply<EPI>(e, y, r0 + r, a, dot);
+    }
+    __syncthreads();
+  }
+  if (EPI == EPI_GP && e.partial) {
+    dot = block_sum(dot, red);
+    if (tid == 0) e.partial[blockIdx.x] = dot;
+  }
+}
+#endif // __HIPCC__
+
+struct SlicedDev {
+  bool built = false;
+  int rows = 0, cols = 0, nsb = 0, S = 0, accrows = 0;
+  DevBuf<int> sbrow, segoff;
+  DevBuf<unsigned> sidx;
+  DevBuf<real> sval;
+  SlicedView view() const { return SlicedView{rows, nsb, S, sbrow.p, segoff.p, sidx.p, sval.p}; }
+  int grid() const { return std::max(1, std::min(nsb, SL_MAX_GRID)); }
+  size_t lds_bytes() const {
+    return (size_t)accrows * sizeof(real) + SL_CHUNK * (sizeof(real) + sizeof(unsigned short)) + 8 * sizeof(real);
+  }
+  // worth it only when the gathered vector overflows an XCD's L2 and rows are short
+  static bool wanted(int cols, const int *hptr, int rows) {
+    if (const char *e = getenv("SCS_AMD_SLICED")) return atoi(e) != 0; // tests force either path
+    if ((size_t)cols * sizeof(real) <= (size_t)3 << 20) return false;
+    long long mx = 0;
+    for (int r = 0; r < rows; ++r) mx = std::max<long long>(mx, hptr[r + 1] - hptr[r]);
+    return mx <= 4 * SL_NNZ_SB;
+  }
+  void build(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval, hipStream_t st) {
+    rows = rows_;
+    cols = cols_;
+    S = std::max(1, (cols + (1 << SL_SLICE_BITS) - 1) >> SL_SLICE_BITS);
+    std::vector<int> sb;
+    sb.push_back(0);
+    int r = 0;
+    while (r < rows) {
+      const int s0 = r;
+      long long acc = 0;
+      while (r < rows && r - s0 < SL_ROWS_MAX) {
+        const long long rn = hptr[r + 1] - hptr[r];
+        if (acc + rn > SL_NNZ_SB && r > s0) break;
+        acc += rn;
+        ++r;
+      }
+      sb.push_back(r);
+    }
+    nsb = (int)sb.size() - 1;
+    accrows = 2;
+    for (int b = 0; b < nsb; ++b) accrows = std::max(accrows, sb[b + 1] - sb[b]);
+    accrows = (accrows + 1) & ~1;
+    const size_t nnz = (size_t)hptr[rows];
+    std::vector<unsigned> hi(nnz ? nnz : 1);
+    std::vector<real> hv(nnz ? nnz : 1);
+    std::vector<int> so((size_t)nsb * (S + 1));
+    std::vector<int> cnt(S + 1), nx(S);
+    for (int b = 0; b < nsb; ++b) {
+      const int k0 = hptr[sb[b]], k1 = hptr[sb[b + 1]];
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int k = k0; k < k1; ++k) cnt[(hidx[k] >> SL_SLICE_BITS) + 1]++;
+      for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
+      for (int s = 0; s <= S; ++s) so[(size_t)b * (S + 1) + s] = k0 + cnt[s];
+      for (int s = 0; s < S; ++s) nx[s] = cnt[s];
+      for (int rr = sb[b]; rr < sb[b + 1]; ++rr)
+        for (int k = hptr[rr]; k < hptr[rr + 1]; ++k) {
+          const int s = hidx[k] >> SL_SLICE_BITS;
+          const size_t q = (size_t)k0 + nx[s]++;
+          hi[q] = (unsigned)(hidx[k] & ((1 << SL_SLICE_BITS) - 1)) | ((unsigned)(rr - sb[b]) << SL_SLICE_BITS);
+          hv[q] = hval[k];
+        }
+    }
+    sbrow.alloc(sb.size());
+    segoff.alloc(so.size());
+    sidx.alloc(nnz ? nnz : 1);
+    sval.alloc(nnz ? nnz : 1);
+    sbrow.upload(sb.data(), sb.size(), st);
+    segoff.upload(so.data(), so.size(), st);
+    if (nnz) {
+      sidx.upload(hi.data(), nnz, st);
+      sval.upload(hv.data(), nnz, st);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    built = true;
+  }
+};
+
+} // namespace scsamd

@@ -104,3 +104,23 @@ def test_with_P_matches_reference():
     assert np.abs(xa - xr).max() <= 1e-8 * np.abs(xr).max()
     amd.scs_free_lin_sys_work(wa)
     ref.scs_free_lin_sys_work(wr)
+
+
+def test_sliced_spmv_path_equals_csr_stream_path(monkeypatch):
+    """The column-sliced kernel (spmv_sliced.h, used when the gathered vector overflows
+    L2) and the CSR-stream kernel solve the same system to the same answer."""
+    amd = capi.load("libscsamd_linsys.so")
+    n, m = 30000, 70001
+    rng = np.random.default_rng(9)
+    A = probgen.random_csc(m, n, 7, seed=5)
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
+    dr = probgen.diag_r(n, m, z=m // 10)
+    b = rng.uniform(-1, 1, n + m)
+    s = rng.uniform(-1, 1, n)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SCS_AMD_SLICED", flag)
+        w, out = _solve_with(amd, prob.matA, None, dr, b, s, 1e-12)
+        amd.scs_free_lin_sys_work(w)
+        outs.append(out)
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-9 * np.abs(outs[0]).max()
