@@ -187,6 +187,15 @@ def main():
             roof["avg_launch_us"] = avg_s * 1e6
             roof["algorithmic_bytes_per_launch"] = bytes_per_spmv
             roof["launches_timed"] = int(spmv_samples)
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this
+        # process); only quoted for the exact workload it was measured on
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if n == 1000000 and m == 2000000 and col_nnz == 10:
+                roof["traffic"] = pj["hbm_bytes_per_launch_mean"]
+                roof["traffic_source"] = "profiles/r1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+        except Exception:
+            pass
         out = {
             "metric": "ADMM iters/sec (+ time-to-eps=1e-4), 1e6-var random SOCP, 1 GPU",
             "value": total_steps / elapsed_max,

@@ -210,6 +210,47 @@ template <int CH> __global__ __launch_bounds__(256) void k_sliced_pf(Sliced A, c
   for (int r = tid; r < nr; r += 256) y[r0 + r] = acc[r];
 }
 
+
+// wave-per-super-block variant: no workgroup barriers at all (a wave's LDS ops are in order)
+template <int CHW, int ACCW> __global__ __launch_bounds__(256) void k_sliced_wave(Sliced A, const double *__restrict__ x, double *y) {
+  __shared__ double acc_all[4][ACCW];
+  __shared__ double sp_all[4][CHW];
+  __shared__ unsigned short sr_all[4][CHW];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wv;
+  if (b >= A.nsb) return;
+  double *acc = acc_all[wv]; double *sp = sp_all[wv]; unsigned short *sr = sr_all[wv];
+  constexpr int U = CHW / 64;
+  const int r0 = A.sbrow[b], nr = A.sbrow[b + 1] - r0;
+  for (int r = lane; r < nr; r += 64) acc[r] = 0;
+  const unsigned mask = (1u << A.SB) - 1;
+  const int *so = A.segoff + (size_t)b * (A.S + 1);
+  for (int s = 0; s < A.S; ++s) {
+    const int e0 = so[s], e1 = so[s + 1];
+    const double *xs = x + ((size_t)s << A.SB);
+    for (int base = e0; base < e1; base += CHW) {
+      const int cnt = min(CHW, e1 - base);
+      unsigned w[U]; double v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) { const int k = lane + j * 64; const bool ok = k < cnt; w[j] = ok ? A.sidx[base + k] : 0u; v[j] = ok ? A.sval[base + k] : 0.0; }
+      double xx[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) xx[j] = xs[w[j] & mask];
+#pragma unroll
+      for (int j = 0; j < U; ++j) { const int k = lane + j * 64; if (k < cnt) { sp[k] = v[j] * xx[j]; sr[k] = (unsigned short)(w[j] >> A.SB); } }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave are visible to its lanes
+#pragma unroll
+      for (int j = 0; j < U; ++j) { const int k = lane + j * 64;
+        if (k < cnt) { const unsigned short lr = sr[k];
+          if (k == 0 || sr[k - 1] != lr) { double sum = sp[k]; int kk = k + 1; while (kk < cnt && sr[kk] == lr) sum += sp[kk++]; acc[lr] += sum; } } }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+  }
+  for (int r = lane; r < nr; r += 64) y[r0 + r] = acc[r];
+}
+
 static int g_maxrows = 0;
 static Sliced build_sliced(int rows, int cols, const std::vector<int> &ptr, const std::vector<int> &idx, const std::vector<double> &val, int SB, int nnz_sb) {
   int S = (cols + (1 << SB) - 1) >> SB;
@@ -331,8 +372,29 @@ int main(int argc, char **argv) {
       }
     };
     long long bA2 = (long long)nnz * 12 + (m + 1) * 4LL + n * 8LL + m * 8LL, bT2 = (long long)nnz * 12 + (n + 1) * 4LL + m * 8LL + n * 8LL;
-    check("A ", m, n, Ap, Ai, Ax, dAp, dAi, dAx, bA2);
-    check("At", n, m, Tp, Ti, Tx, dTp, dTi, dTx, bT2);
+
+    auto checkw = [&](const char *name, int rows, int cols, const std::vector<int> &P, const std::vector<int> &I, const std::vector<double> &V, int *dp, int *di, double *dv, long long bytes) {
+      Csr C{rows, cols, 0, dp, di, nullptr, dv};
+      hipLaunchKernelGGL(k_csr_scalar, dim3(8192), dim3(256), 0, 0, C, dxm, dref);
+      std::vector<double> h1(rows), h2(rows); CK(hipMemcpy(h1.data(), dref, rows * 8, hipMemcpyDeviceToHost));
+      for (int SB : {16, 17}) for (int nnz_sb : {1024, 2048, 4096}) {
+        Sliced A = build_sliced(rows, cols, P, I, V, SB, nnz_sb);
+        if (g_maxrows > 1024) { printf("%s wave SB=%d nnz_sb=%d: maxrows %d too large\n", name, SB, nnz_sb, g_maxrows); continue; }
+        int g = (A.nsb + 3) / 4;
+        CK(hipMemset(dys, 0, rows * 8));
+        hipLaunchKernelGGL((k_sliced_wave<128, 1024>), dim3(g), dim3(256), 0, 0, A, dxm, dys);
+        CK(hipMemcpy(h2.data(), dys, rows * 8, hipMemcpyDeviceToHost));
+        double err = 0; for (int i = 0; i < rows; ++i) err = std::max(err, fabs(h1[i] - h2[i]));
+        double u1 = time_us([&] { hipLaunchKernelGGL((k_sliced_wave<128, 1024>), dim3(g), dim3(256), 0, 0, A, dxm, dys); });
+        double u2 = time_us([&] { hipLaunchKernelGGL((k_sliced_wave<256, 1024>), dim3(g), dim3(256), 0, 0, A, dxm, dys); });
+        double u3 = time_us([&] { hipLaunchKernelGGL((k_sliced_wave<64, 1024>), dim3(g), dim3(256), 0, 0, A, dxm, dys); });
+        printf("%s WAVE SB=%d (S=%d) nnz_sb=%d nsb=%d maxrows=%d: CHW128 %.1f | CHW256 %.1f | CHW64 %.1f us (%.0f GB/s best) err %.1e\n", name, SB, A.S, nnz_sb, A.nsb, g_maxrows, u1, u2, u3, bytes / std::min(u1, std::min(u2, u3)) / 1e3, err);
+        CK(hipFree((void*)A.sbrow)); CK(hipFree((void*)A.segoff)); CK(hipFree((void*)A.sidx)); CK(hipFree((void*)A.sval));
+      }
+    };
+    checkw("A ", m, n, Ap, Ai, Ax, dAp, dAi, dAx, bA2);
+    checkw("At", n, m, Tp, Ti, Tx, dTp, dTi, dTx, bT2);
+
   }
   // (3) csr_stream variants
   auto run = [&](const char *name, int rows, int cols, int *p, int *i, double *v, double *x, long long bytes) {

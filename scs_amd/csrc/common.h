@@ -190,6 +190,13 @@ __device__ __forceinline__ T reduce_partials_max(const T *part, int count, T *sh
   return block_max(s, sh);
 }
 template <typename T> __device__ __forceinline__ T absval(T x) { return x < 0 ? -x : x; }
+// 16-byte vector access for the streaming elementwise kernels (dwordx4 per lane)
+constexpr int RVW = 16 / sizeof(scs_float);
+struct alignas(16) rvec {
+  scs_float v[RVW];
+};
+__device__ __forceinline__ rvec ldv(const scs_float *p, size_t iv) { return reinterpret_cast<const rvec *>(p)[iv]; }
+__device__ __forceinline__ void stv(scs_float *p, size_t iv, const rvec &x) { reinterpret_cast<rvec *>(p)[iv] = x; }
 #endif // __HIPCC__
 
 } // namespace scsamd

@@ -153,7 +153,27 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, re
   const real pgp = reduce_partials_sum(part_pgp, cnt_pgp, red);
   const real alpha = ctl->ztr[parity] / pgp;
   real ztr = 0, mx = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+  const int nv = n / RVW;
+  for (int iv = gtid; iv < nv; iv += gs) { // 16 B per lane per array
+    const rvec P = ldv(p, iv), G = ldv(Gp, iv), Mv = ldv(M, iv);
+    rvec X = ldv(x, iv), R = ldv(r, iv), Z;
+#pragma unroll
+    for (int e = 0; e < RVW; ++e) {
+      X.v[e] += alpha * P.v[e];
+      const real ri = R.v[e] + (-alpha) * G.v[e];
+      R.v[e] = ri;
+      const real zi = ri * Mv.v[e];
+      Z.v[e] = zi;
+      ztr += zi * ri;
+      const real a = absval(ri);
+      mx = a > mx ? a : mx;
+    }
+    stv(x, iv, X);
+    stv(r, iv, R);
+    stv(z, iv, Z);
+  }
+  for (int i = nv * RVW + gtid; i < n; i += gs) {
     const real pi = p[i], gi = Gp[i];
     x[i] += alpha * pi;
     const real ri = r[i] + (-alpha) * gi;
@@ -186,8 +206,16 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const re
   const bool brk = !conv && ztr_prev == (real)0;
   if (!conv && !brk) {
     const real beta = ztr / ztr_prev;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-      p[i] = z[i] + beta * p[i];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+    const int nv = n / RVW;
+    for (int iv = gtid; iv < nv; iv += gs) {
+      const rvec Z = ldv(z, iv);
+      rvec P = ldv(p, iv);
+#pragma unroll
+      for (int e = 0; e < RVW; ++e) P.v[e] = Z.v[e] + beta * P.v[e];
+      stv(p, iv, P);
+    }
+    for (int i = nv * RVW + gtid; i < n; i += gs) p[i] = z[i] + beta * p[i];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     ctl->ztr[parity ^ 1] = ztr;
