@@ -343,7 +343,7 @@ struct Resid { // reference include/scs_work.h:32-52 (scalars) + the norms the l
 };
 
 struct SCS_WORK {
-  int n = 0, m = 0, l = 0;
+  int n = 0, m = 0, l = 0, device = 0;
   ScsSettings stgs;
   // deep copies (host)
   std::vector<int> cq, cs;
@@ -813,7 +813,9 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
   try {
     if (scs_amd_device_count() <= 0)
       throw HipError("scs_amd: no HIP device visible -- this backend has no CPU fallback");
+    HIP_CHECK(hipSetDevice(selected_device()));
     w = new ScsWork();
+    w->device = selected_device();
     const int n = w->n = d->n, m = w->m = d->m, l = w->l = d->n + d->m + 1;
     w->stgs = *stgs;
     if (stgs->write_data_filename)
@@ -901,6 +903,7 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
 // can time / inspect an exact range of iterations; scs_solve is begin + steps + end.
 static void solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) {
   const int n = w->n, m = w->m, l = w->l;
+  HIP_CHECK(hipSetDevice(w->device)); // callers may be worker threads
   hipStream_t st = w->stream;
   w->t_solve0 = now_ms();
   w->t_lin = w->t_accel = 0;
@@ -950,6 +953,7 @@ static void solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) 
 // convergence / time limit (loop_done).  Returns <0 on failure.
 static int solve_steps(ScsWork *w, int upto) {
   const int n = w->n, m = w->m, l = w->l;
+  HIP_CHECK(hipSetDevice(w->device));
   hipStream_t st = w->stream;
   const int gl = glue_grid(l), gnm = glue_grid(n + m);
   real *rp_part = w->part.p; // root_plus partials reuse the residual partial area (5 rows)
@@ -1050,6 +1054,7 @@ static int solve_steps(ScsWork *w, int upto) {
 
 static void solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info) {
   const int i = w->cur_iter;
+  HIP_CHECK(hipSetDevice(w->device));
   strcpy(info->lin_sys_solver, scs_get_lin_sys_method());
   info->status_val = w->run_status;
   if (w->stgs.verbose) {

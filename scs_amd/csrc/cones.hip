@@ -32,7 +32,7 @@ constexpr int SOC_TILE = 2048;
 constexpr int BOX_THREADS = 1024;
 constexpr int BOX_MAX_ITERS = 25;     // BOX_CONE_MAX_ITERS, cones.c:21
 constexpr double MAX_BOX_VAL = 1e15;  // cones.c:54
-constexpr int PSD_THREADS = 256;
+constexpr int PSD_THREADS = 512;
 constexpr int PSD_LDS_KMAX = 92;      // 2*92*93*8 B + 12 KB header = 149 KB < 160 KB
 constexpr int PSD_MAX_SWEEPS = 30;
 constexpr int PSD_MAX_PAIRS = 512;    // supports k <= 1024
@@ -254,61 +254,60 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     if (tid == 0) X[0] = X[0] > (real)0 ? X[0] : (real)0;
     return;
   }
-  const int ld = k | 1; // odd leading dimension: conflict-free column walks
-  const int ldm = kmax | 1;
-  real *A = use_lds ? lds_mat : scratch + (size_t)cone * 2 * kmax * ldm;
-  real *V = A + (size_t)k * ld;
+  // pad to an even order K2 with a zero row/column: the odd index pairs with the dummy
+  // (identity rotation), so every step is npairs full 2x2-block updates
+  const int K2 = (k + 1) & ~1;
+  const int npairs = K2 / 2;
+  const int ld = K2 | 1; // odd leading dimension: conflict-free row and column walks
+  const int K2m = (kmax + 1) & ~1, ldm = K2m | 1;
+  real *A = use_lds ? lds_mat : scratch + (size_t)cone * 2 * K2m * ldm;
+  real *V = A + (size_t)K2 * ld;
   const real sqrt2 = sqrt((real)2);
   // unpack: full symmetric, diagonal * sqrt(2)  (cones.c:1018-1025)
-  for (int e = tid; e < k * k; e += PSD_THREADS) {
-    const int i = e % k, j = e / k;
-    const int hi = i > j ? i : j, lo = i > j ? j : i;
-    real v = X[packed_index(hi, lo, k)];
-    if (i == j) v *= sqrt2;
+  for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+    const int i = e % K2, j = e / K2;
+    real v = 0;
+    if (i < k && j < k) {
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      v = X[packed_index(hi, lo, k)];
+      if (i == j) v *= sqrt2;
+    }
     A[i * ld + j] = v;
     V[i * ld + j] = i == j ? (real)1 : (real)0;
   }
   __syncthreads();
-  // Frobenius norm for the stopping test
   real fro = 0;
-  for (int e = tid; e < k * k; e += PSD_THREADS) {
-    const real v = A[(e / k) * ld + (e % k)];
+  for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+    const real v = A[(e / K2) * ld + (e % K2)];
     fro += v * v;
   }
   fro = sqrt(block_sum(fro, red));
-  const int K2 = (k + 1) & ~1; // even number of players, index k == bye
-  const int npairs = K2 / 2;
   const real eps = sizeof(real) == 8 ? (real)1e-15 : (real)1e-7;
   int sweep = 0;
   if (fro > (real)0) {
     for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
       real offmax = 0;
       for (int step = 0; step < K2 - 1; ++step) {
-        // round-robin pairing: player 0 fixed, others rotate
+        // round-robin pairing: player 0 fixed, the others rotate
         if (tid < npairs) {
           const int i = tid;
           int p = i == 0 ? 0 : 1 + ((i - 1 + step) % (K2 - 1));
-          const int jj = K2 - 1 - i;
-          int q = 1 + ((jj - 1 + step) % (K2 - 1));
+          int q = 1 + ((K2 - 2 - i + step) % (K2 - 1));
           if (p > q) {
             const int t = p;
             p = q;
             q = t;
           }
           real c = 1, s = 0;
-          if (q < k) {
-            const real apq = A[p * ld + q];
-            const real aa = absval(apq);
-            offmax = aa > offmax ? aa : offmax;
-            if (aa > (real)0) {
-              const real app = A[p * ld + p], aqq = A[q * ld + q];
-              const real theta = (aqq - app) / ((real)2 * apq);
-              const real t = (theta >= 0 ? (real)1 : (real)-1) / (absval(theta) + sqrt(theta * theta + (real)1));
-              c = (real)1 / sqrt(t * t + (real)1);
-              s = t * c;
-            }
-          } else {
-            q = -1;
+          const real apq = A[p * ld + q];
+          const real aa = absval(apq);
+          if (q < k) offmax = aa > offmax ? aa : offmax;
+          if (q < k && aa > (real)0) {
+            const real app = A[p * ld + p], aqq = A[q * ld + q];
+            const real theta = (aqq - app) / ((real)2 * apq);
+            const real t = (theta >= 0 ? (real)1 : (real)-1) / (absval(theta) + sqrt(theta * theta + (real)1));
+            c = (real)1 / sqrt(t * t + (real)1);
+            s = t * c;
           }
           rot_p[i] = p;
           rot_q[i] = q;
@@ -316,31 +315,29 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
           rot_s[i] = s;
         }
         __syncthreads();
-        // rows: A <- J' A
-        for (int e = tid; e < npairs * k; e += PSD_THREADS) {
-          const int pr = e / k, j = e % k;
-          const int q = rot_q[pr];
-          if (q < 0) continue;
-          const int p = rot_p[pr];
-          const real c = rot_c[pr], s = rot_s[pr];
-          const real ap = A[p * ld + j], aq = A[q * ld + j];
-          A[p * ld + j] = c * ap - s * aq;
-          A[q * ld + j] = s * ap + c * aq;
-        }
-        __syncthreads();
-        // columns: A <- A J ; V <- V J
-        for (int e = tid; e < npairs * k; e += PSD_THREADS) {
-          const int pr = e / k, i = e % k;
-          const int q = rot_q[pr];
-          if (q < 0) continue;
-          const int p = rot_p[pr];
-          const real c = rot_c[pr], s = rot_s[pr];
-          const real ap = A[i * ld + p], aq = A[i * ld + q];
-          A[i * ld + p] = c * ap - s * aq;
-          A[i * ld + q] = s * ap + c * aq;
-          const real vp = V[i * ld + p], vq = V[i * ld + q];
-          V[i * ld + p] = c * vp - s * vq;
-          V[i * ld + q] = s * vp + c * vq;
+        // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q);
+        // V <- V J over (row, pair) items.  One barrier per step for both.
+        const int nblk = npairs * npairs, nv = K2 * npairs;
+        for (int e = tid; e < nblk + nv; e += PSD_THREADS) {
+          if (e < nblk) {
+            const int P = e / npairs, Q = e % npairs;
+            const int p1 = rot_p[P], q1 = rot_q[P], p2 = rot_p[Q], q2 = rot_q[Q];
+            const real c1 = rot_c[P], s1 = rot_s[P], c2 = rot_c[Q], s2 = rot_s[Q];
+            const real a11 = A[p1 * ld + p2], a12 = A[p1 * ld + q2], a21 = A[q1 * ld + p2], a22 = A[q1 * ld + q2];
+            const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
+            const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
+            A[p1 * ld + p2] = c2 * r11 - s2 * r12;
+            A[p1 * ld + q2] = s2 * r11 + c2 * r12;
+            A[q1 * ld + p2] = c2 * r21 - s2 * r22;
+            A[q1 * ld + q2] = s2 * r21 + c2 * r22;
+          } else {
+            const int f = e - nblk, i = f / npairs, Q = f % npairs;
+            const int p2 = rot_p[Q], q2 = rot_q[Q];
+            const real c2 = rot_c[Q], s2 = rot_s[Q];
+            const real vp = V[i * ld + p2], vq = V[i * ld + q2];
+            V[i * ld + p2] = c2 * vp - s2 * vq;
+            V[i * ld + q2] = s2 * vp + c2 * vq;
+          }
         }
         __syncthreads();
       }
@@ -349,35 +346,59 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     }
   }
   if (sweep >= PSD_MAX_SWEEPS && tid == 0) atomicMax(status, 1); // did not converge (positive: not fatal)
-  // eigenvalues = diag(A); scale columns of V by sqrt(max(lambda, 0)) into W (re-using A)
-  // W[i][c] = V[i][c] * sqrt(lambda_c) for lambda_c > 0 else 0   (cones.c:1036-1044)
+  // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044); lambda = diag(A)
   __syncthreads();
-  for (int cidx = tid; cidx < k; cidx += PSD_THREADS) {
+  for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+    const int i = e / K2, cidx = e % K2;
     const real lam = A[cidx * ld + cidx];
-    A[cidx * ld + cidx] = lam > (real)0 ? sqrt(lam) : (real)0;
-  }
-  __syncthreads();
-  for (int e = tid; e < k * k; e += PSD_THREADS) {
-    const int i = e / k, cidx = e % k;
-    V[i * ld + cidx] *= A[cidx * ld + cidx];
+    V[i * ld + cidx] *= (cidx < k && lam > (real)0) ? sqrt(lam) : (real)0;
   }
   __syncthreads();
   // X+ = W W', lower triangle only, repack with diagonal / sqrt(2)  (cones.c:1052-1063)
   const real inv_sqrt2 = (real)1 / sqrt2;
-  const int ntri = k * (k + 1) / 2;
-  for (int e = tid; e < ntri; e += PSD_THREADS) {
-    // invert packed index -> (i, j): walk columns
-    int j = 0, rem = e;
-    while (rem >= k - j) {
-      rem -= k - j;
-      ++j;
+#ifndef SFLOAT
+  // fp64 matrix cores: D(16x16) += A(16x4) B(4x16), v_mfma_f64_16x16x4_f64.  Lane l holds
+  // A[l&15][l>>4], B[l>>4][l&15]; D element (row = (l>>4) + 4*reg, col = l&15), reg 0..3.
+  {
+    const int wave = tid >> 6, lane = tid & 63, nw = PSD_THREADS >> 6;
+    const int T = (k + 15) >> 4; // 16x16 tiles per dimension
+    const int ksteps = (K2 + 3) >> 2;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < T * T; t += nw) {
+      const int ti = t / T, tj = t % T;
+      if (tj > ti) continue; // lower triangle of tiles
+      f64x4 acc = {0, 0, 0, 0};
+      const int ra = ti * 16 + li, rb = tj * 16 + li;
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int kc = ks * 4 + lk;
+        const double av = (ra < k && kc < K2) ? V[ra * ld + kc] : 0.0;
+        const double bv = (rb < k && kc < K2) ? V[rb * ld + kc] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
+        if (i < k && j <= i) X[packed_index(i, j, k)] = i == j ? acc[r] * inv_sqrt2 : acc[r];
+      }
     }
-    const int i = j + rem;
-    real acc = 0;
-    for (int cidx = 0; cidx < k; ++cidx) acc += V[i * ld + cidx] * V[j * ld + cidx];
-    if (i == j) acc *= inv_sqrt2;
-    X[e] = acc;
   }
+#else
+  {
+    const int ntri = k * (k + 1) / 2;
+    for (int e = tid; e < ntri; e += PSD_THREADS) {
+      int j = 0, rem = e;
+      while (rem >= k - j) {
+        rem -= k - j;
+        ++j;
+      }
+      const int i = j + rem;
+      real acc = 0;
+      for (int cidx = 0; cidx < k; ++cidx) acc += V[i * ld + cidx] * V[j * ld + cidx];
+      if (i == j) acc *= inv_sqrt2;
+      X[e] = acc;
+    }
+  }
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -513,7 +534,7 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   up(psd_off, poff);
   up(psd_k, pk);
   if (n_psd && psd_kmax > PSD_LDS_KMAX)
-    psd_work.alloc((size_t)n_psd * 2 * psd_kmax * (psd_kmax | 1));
+    psd_work.alloc((size_t)n_psd * 2 * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
   status.alloc(1);
   HIP_CHECK(hipStreamSynchronize(stream));
   if (off != m) throw HipError("scs_amd: cone rows do not add up to m");
@@ -539,7 +560,8 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
   }
   if (n_psd) {
     const int use_lds = psd_kmax <= PSD_LDS_KMAX;
-    const size_t lds = PSD_LDS_HEADER + (use_lds ? (size_t)2 * psd_kmax * (psd_kmax | 1) * sizeof(real) : 0);
+    const int K2m = (psd_kmax + 1) & ~1;
+    const size_t lds = PSD_LDS_HEADER + (use_lds ? (size_t)2 * K2m * (K2m | 1) * sizeof(real) : 0);
     if (lds > 48 * 1024)
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_psd_jacobi),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

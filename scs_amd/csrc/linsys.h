@@ -8,6 +8,8 @@
 
 namespace scsamd {
 
+int selected_device(); // device chosen by scs_amd_set_device (HIP's current device is per host thread)
+
 // Control block of one PCG solve, lives in device memory; the host reads it back
 // once per enqueued batch of iterations.
 struct CgCtl {

@@ -533,6 +533,9 @@ struct SCS_LIN_SYS_WORK {
 };
 
 static int g_device = 0;
+namespace scsamd {
+int selected_device() { return g_device; }
+}
 
 extern "C" {
 
