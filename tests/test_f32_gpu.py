@@ -1,0 +1,26 @@
+"""BASELINE configs[4] in miniature: the -DSFLOAT build (libscsamd_f32.so) against the
+reference's SFLOAT=1 build on the same inputs; tolerance 1e-3 as the config states (the
+reference documents SFLOAT as "currently broken", docs/src/api/compile_flags.rst:25-28)."""
+import numpy as np
+import pytest
+
+from scs_amd import capi, problems
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fp32_solve_matches_fp32_reference_loosely():
+    from oracle import pyoracle
+    if not pyoracle.ref_available("libscsindir_ref_f32.so"):
+        pytest.skip("oracle/_ref f32 flavour not built")
+    ref = pyoracle.load_ref("libscsindir_ref_f32.so")
+    amd = capi.load("libscsamd_f32.so")
+    pr = problems.random_socp(400, 1200, 8, seed=4, dtype=np.float32)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=capi.T32)
+    kw = dict(verbose=0, acceleration_lookback=0, eps_abs=1e-3, eps_rel=1e-3, max_iters=5000)
+    ra, rr = capi.solve(amd, prob, **kw), capi.solve(ref, prob, **kw)
+    assert ra["info"]["status_val"] in (1, 2) and rr["info"]["status_val"] in (1, 2)
+    scale = max(1.0, abs(rr["info"]["pobj"]))
+    assert abs(ra["info"]["pobj"] - rr["info"]["pobj"]) <= 2e-2 * scale
+    popt = float(pr["c"].astype(np.float64) @ pr["x_opt"])
+    assert abs(ra["info"]["pobj"] - popt) <= 2e-2 * max(1.0, abs(popt))
