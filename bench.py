@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-sample-i0", type=int, default=20)
     ap.add_argument("--cpu-sample-iters", type=int, default=25)
     ap.add_argument("--max-iters", type=int, default=20000)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f32 = the -DSFLOAT library (BASELINE configs[4]; residual tolerance relaxed to 1e-3)")
+    ap.add_argument("--eps", type=float, default=0.0, help="eps_abs = eps_rel (default 1e-4; 1e-3 with --dtype f32)")
     return ap.parse_args()
 
 
@@ -100,9 +103,10 @@ def main():
         dist = dist_
         dist.init_process_group(backend="nccl")  # RCCL
     from scs_amd import capi, problems
-    lib = capi.load("libscsamd.so")
+    lib = capi.load("libscsamd_f32.so" if args.dtype == "f32" else "libscsamd.so")
     T = lib._scs_types
     assert lib.scs_amd_set_device(local_rank) == 0
+    eps = args.eps or (1e-3 if args.dtype == "f32" else 1e-4)
 
     # ---- batch descriptor: rank 0 decides, RCCL broadcast (launch) -------------
     desc = torch.tensor([n, m, args.col_nnz, args.seed, args.steps, args.warmup, args.aa], dtype=torch.int64,
@@ -113,16 +117,17 @@ def main():
 
     # ---- synthetic problem, one per rank (seed + rank) --------------------------
     t0 = time.time()
-    pr = problems.random_socp(n, m, col_nnz, seed=seed + rank)
-    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    pr = problems.random_socp(n, m, col_nnz, seed=seed + rank, dtype=T.np_float)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
     t_gen = time.time() - t0
-    st = capi.default_settings(lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters)
+    st = capi.default_settings(lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters, eps_abs=eps,
+                               eps_rel=eps)
     t0 = time.time()
     w = lib.scs_init(C.byref(prob.data), C.byref(prob.k), C.byref(st))
     if not w:
         raise SystemExit("scs_init failed")
     t_init = time.time() - t0
-    x = np.zeros(n); y = np.zeros(m); s = np.zeros(m)
+    x = np.zeros(n, dtype=T.np_float); y = np.zeros(m, dtype=T.np_float); s = np.zeros(m, dtype=T.np_float)
     sol = T.ScsSolution(x.ctypes.data_as(T.fp), y.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp))
     info = T.ScsInfo()
 
@@ -182,7 +187,7 @@ def main():
         cg_its = stats1.cg_iters - stats0.cg_iters
         spmv_samples = stats1.spmv_launches - stats0.spmv_launches
         spmv_ms = stats1.spmv_ms - stats0.spmv_ms
-        bytes_per_spmv = stats1.spmv_bytes / 2.0
+        bytes_per_spmv = stats1.spmv_bytes / 2.0  # already computed with sizeof(scs_float) of the library
         roof = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
                     kernel="csr_sliced_kernel / csr_stream_kernel (CSR SpMV, both orientations)")
         if spmv_samples > 0 and spmv_ms > 0:
@@ -212,7 +217,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"random SOCP n={n} m={m} nnz={n*col_nnz} (BASELINE configs[1]); "
                                    f"cones z={pr['cone']['z']} l={pr['cone']['l']} soc={len(pr['cone']['q'])}; "
@@ -228,7 +233,8 @@ def main():
             "setup_s": {"generate": t_gen, "scs_init": t_init},
             "results_per_rank": [[float(v) for v in r.tolist()] for r in recs],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        out["eps"] = eps
+        if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
             out["cpu_baseline"] = cpu_baseline(args, n)
         else:
             out["cpu_baseline"] = None

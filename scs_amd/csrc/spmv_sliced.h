@@ -25,9 +25,11 @@
 
 namespace scsamd {
 
-constexpr int SL_SLICE_BITS = 16;  // columns per slice = 65536
-constexpr int SL_NNZ_SB = 8192;    // nonzeros per super-block (target)
-constexpr int SL_ROWS_MAX = 4096;  // rows per super-block (LDS accumulators)
+// columns per slice: 512 KB of x either way (2^16 doubles / 2^17 floats)
+constexpr int SL_SLICE_BITS = sizeof(real) == 8 ? 16 : 17;
+constexpr int SL_NNZ_SB = 8192;    // nonzeros per super-block (minimum target)
+constexpr int SL_ROWS_MAX = 32768 / sizeof(real); // rows per super-block: 32 KB of LDS accumulators
+constexpr int SL_TARGET_WGS = 1400; // keep every workgroup resident (time alignment needs one wave of WGs)
 constexpr int SL_CHUNK = 512;      // products staged per step
 constexpr int SL_MAX_GRID = 16384;
 
@@ -139,12 +141,13 @@ struct SlicedDev {
     std::vector<int> sb;
     sb.push_back(0);
     int r = 0;
+    const long long nnz_sb = std::max<long long>(SL_NNZ_SB, ((long long)hptr[rows] + SL_TARGET_WGS - 1) / SL_TARGET_WGS);
     while (r < rows) {
       const int s0 = r;
       long long acc = 0;
       while (r < rows && r - s0 < SL_ROWS_MAX) {
         const long long rn = hptr[r + 1] - hptr[r];
-        if (acc + rn > SL_NNZ_SB && r > s0) break;
+        if (acc + rn > nnz_sb && r > s0) break;
         acc += rn;
         ++r;
       }
