@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--aa", type=int, default=0, help="acceleration_lookback (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-eps", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=50000)
+    ap.add_argument("--cpu-sample-n", type=int, default=30000)
     ap.add_argument("--cpu-sample-i0", type=int, default=20)
     ap.add_argument("--cpu-sample-iters", type=int, default=25)
     ap.add_argument("--max-iters", type=int, default=20000)
