@@ -253,6 +253,68 @@ template <int CHW, int ACCW> __global__ __launch_bounds__(256) void k_sliced_wav
   for (int r = lane; r < nr; r += 64) y[r0 + r] = acc[r];
 }
 
+
+// two-deep software pipeline: gathers of chunk c+1 and the idx/val loads of chunk c+2 are in
+// flight while chunk c is reduced in LDS
+template <int CH> __global__ __launch_bounds__(256) void k_sliced_pf2(Sliced A, const double *__restrict__ x, double *y, int accrows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *acc = reinterpret_cast<double *>(smem);
+  double *sp = acc + accrows;
+  unsigned short *sr = reinterpret_cast<unsigned short *>(sp + CH);
+  constexpr int U = CH / 256;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int r0 = A.sbrow[b], nr = A.sbrow[b + 1] - r0;
+  for (int r = tid; r < nr; r += 256) acc[r] = 0;
+  const unsigned mask = (1u << A.SB) - 1;
+  const int *so = A.segoff + (size_t)b * (A.S + 1);
+  // cursor helper: advance (s, base) past the chunk [base, base+cnt)
+  auto advance = [&](int &s, int &base, int cnt) { base += cnt; while (s < A.S && base >= so[s + 1]) ++s; };
+  auto chunk_cnt = [&](int s, int base) { return s < A.S ? min(CH, so[s + 1] - base) : 0; };
+  int s0 = 0, b0 = so[0]; while (s0 < A.S && b0 >= so[s0 + 1]) ++s0;
+  int c0 = chunk_cnt(s0, b0);
+  unsigned w0[U]; double v0[U], x0[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const int k = tid + j * 256; const bool ok = k < c0; w0[j] = ok ? A.sidx[b0 + k] : 0u; v0[j] = ok ? A.sval[b0 + k] : 0.0; }
+  int s1 = s0, b1 = b0; advance(s1, b1, c0);
+  int c1 = chunk_cnt(s1, b1);
+  unsigned w1[U]; double v1[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const int k = tid + j * 256; const bool ok = k < c1; w1[j] = ok ? A.sidx[b1 + k] : 0u; v1[j] = ok ? A.sval[b1 + k] : 0.0; }
+  {
+    const double *xs = x + ((size_t)(s0 < A.S ? s0 : 0) << A.SB);
+#pragma unroll
+    for (int j = 0; j < U; ++j) x0[j] = xs[w0[j] & mask];
+  }
+  __syncthreads();
+  while (c0 > 0) {
+    // issue gathers for chunk 1 and loads for chunk 2 BEFORE consuming chunk 0
+    double x1[U];
+    {
+      const double *xs1 = x + ((size_t)(s1 < A.S ? s1 : 0) << A.SB);
+#pragma unroll
+      for (int j = 0; j < U; ++j) x1[j] = xs1[w1[j] & mask];
+    }
+    int s2 = s1, b2 = b1; advance(s2, b2, c1);
+    const int c2 = chunk_cnt(s2, b2);
+    unsigned w2[U]; double v2[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int k = tid + j * 256; const bool ok = k < c2; w2[j] = ok ? A.sidx[b2 + k] : 0u; v2[j] = ok ? A.sval[b2 + k] : 0.0; }
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int k = tid + j * 256; if (k < c0) { sp[k] = v0[j] * x0[j]; sr[k] = (unsigned short)(w0[j] >> A.SB); } }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const int k = tid + j * 256;
+      if (k < c0) { const unsigned short lr = sr[k];
+        if (k == 0 || sr[k - 1] != lr) { double sum = sp[k]; int kk = k + 1; while (kk < c0 && sr[kk] == lr) sum += sp[kk++]; acc[lr] += sum; } } }
+    __syncthreads();
+    c0 = c1; s0 = s1; b0 = b1;
+    c1 = c2; s1 = s2; b1 = b2;
+#pragma unroll
+    for (int j = 0; j < U; ++j) { w0[j] = w1[j]; v0[j] = v1[j]; x0[j] = x1[j]; w1[j] = w2[j]; v1[j] = v2[j]; }
+  }
+  for (int r = tid; r < nr; r += 256) y[r0 + r] = acc[r];
+}
+
 static int g_maxrows = 0;
 static Sliced build_sliced(int rows, int cols, const std::vector<int> &ptr, const std::vector<int> &idx, const std::vector<double> &val, int SB, int nnz_sb) {
   int S = (cols + (1 << SB) - 1) >> SB;
@@ -352,7 +414,7 @@ int main(int argc, char **argv) {
     auto check = [&](const char *name, int rows, int cols, const std::vector<int> &P, const std::vector<int> &I, const std::vector<double> &V, int *dp, int *di, double *dv, long long bytes) {
       Csr C{rows, cols, 0, dp, di, nullptr, dv};
       hipLaunchKernelGGL(k_csr_scalar, dim3(8192), dim3(256), 0, 0, C, dxm, dref);
-      for (int SB : {15, 16, 17}) for (int nnz_sb : {6144, 8192}) {
+      for (int SB : {16, 17, 18}) for (int nnz_sb : {8192}) {
         Sliced A = build_sliced(rows, cols, P, I, V, SB, nnz_sb);
         int ar = (g_maxrows + 1) & ~1;
         size_t l2 = (size_t)ar * 8 + 2048 * 10, l1 = (size_t)ar * 8 + 1024 * 10, l0 = (size_t)ar * 8 + 512 * 10;
@@ -369,6 +431,13 @@ int main(int argc, char **argv) {
         CK(hipMemset(dys, 0, rows * 8));
         hipLaunchKernelGGL((k_sliced_pf<1024>), dim3(A.nsb), dim3(256), l1, 0, A, dxm, dys, ar);
         { std::vector<double> h3(rows); CK(hipMemcpy(h3.data(), dys, rows * 8, hipMemcpyDeviceToHost)); double e3 = 0; for (int i = 0; i < rows; ++i) e3 = std::max(e3, fabs(h1[i] - h3[i])); printf("   PF: CH2048 %.1f | CH1024 %.1f | CH512 %.1f us  err %.1e\n", p2, p1, p0, e3); }
+        { CK(hipMemset(dys, 0, rows * 8));
+          hipLaunchKernelGGL((k_sliced_pf2<512>), dim3(A.nsb), dim3(256), l0, 0, A, dxm, dys, ar);
+          std::vector<double> h3(rows); CK(hipMemcpy(h3.data(), dys, rows * 8, hipMemcpyDeviceToHost)); double e3 = 0; for (int i = 0; i < rows; ++i) e3 = std::max(e3, fabs(h1[i] - h3[i]));
+          double q0 = time_us([&] { hipLaunchKernelGGL((k_sliced_pf2<256>), dim3(A.nsb), dim3(256), l0, 0, A, dxm, dys, ar); });
+          double q1 = time_us([&] { hipLaunchKernelGGL((k_sliced_pf2<512>), dim3(A.nsb), dim3(256), l0, 0, A, dxm, dys, ar); });
+          double q2 = time_us([&] { hipLaunchKernelGGL((k_sliced_pf2<1024>), dim3(A.nsb), dim3(256), l1, 0, A, dxm, dys, ar); });
+          printf("   PF2 (2-deep pipeline): CH256 %.1f | CH512 %.1f | CH1024 %.1f us  err %.1e\n", q0, q1, q2, e3); }
         { double n1 = time_us([&] { hipLaunchKernelGGL((k_sliced<1024, 1>), dim3(A.nsb), dim3(256), l1, 0, A, dxm, dys, ar); });
           double n0 = time_us([&] { hipLaunchKernelGGL((k_sliced<512, 1>), dim3(A.nsb), dim3(256), l0, 0, A, dxm, dys, ar); });
           printf("   NT streams: CH1024 %.1f | CH512 %.1f us\n", n1, n0); }

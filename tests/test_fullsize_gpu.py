@@ -1,0 +1,71 @@
+"""BASELINE configs[1] at FULL size (n=1e6, m=2e6, nnz=1e7) through size-independent
+properties -- the oracle cannot run at this size in seconds, the identities can:
+KKT residual of the linear solve, residual / objective identities of the returned
+(x, y, s) recomputed independently (test/problem_utils.h:107-249 style), cone membership,
+complementarity, determinism."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from scs_amd import capi, problems
+
+pytestmark = pytest.mark.gpu
+N, M, CN = 1000000, 2000000, 10
+
+
+@pytest.fixture(scope="module")
+def full_problem():
+    pr = problems.random_socp(N, M, CN, seed=1234)
+    return pr, capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+
+
+def test_linear_solve_kkt_identity_at_full_size(full_problem):
+    pr, prob = full_problem
+    lib = capi.load("libscsamd_linsys.so")
+    T = lib._scs_types
+    rng = np.random.default_rng(0)
+    dr = np.empty(N + M)
+    dr[:N] = 1e-2                      # well conditioned on purpose: this checks the kernels, not CG
+    dr[N:] = 1.0
+    w = lib.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
+    assert w
+    b = rng.uniform(-1, 1, N + M)
+    out = b.copy()
+    assert lib.scs_solve_lin_sys(w, out.ctypes.data_as(T.fp), None, 1e-10) == 0
+    x, y = out[:N], out[N:]
+    A = prob.sparse()
+    r2 = A @ x - dr[N:] * y - b[N:]            # second block row exact by construction
+    assert np.abs(r2).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    r1 = dr[:N] * x + A.T @ y - b[:N]          # first block row to the CG tolerance
+    assert np.abs(r1).max() <= 1e-10 * 1.01 + 1e-13
+    # linearity: solving 2b gives 2[x; y]
+    out2 = 2 * b
+    assert lib.scs_solve_lin_sys(w, out2.ctypes.data_as(T.fp), None, 1e-10) == 0
+    assert np.abs(out2 - 2 * out).max() <= 1e-8 * np.abs(out).max()
+    lib.scs_free_lin_sys_work(w)
+
+
+def test_capped_solve_identities_and_cone_membership_at_full_size(full_problem):
+    pr, prob = full_problem
+    lib = capi.load("libscsamd.so")
+    r = capi.solve(lib, prob, verbose=0, acceleration_lookback=0, max_iters=150, want_stats=True)
+    info, x, y, s = r["info"], r["x"], r["y"], r["s"]
+    assert info["status_val"] == 2 and "max_iters" in info["status"]      # solved (inaccurate)
+    A = prob.sparse()
+    res_pri = np.abs(A @ x + s - prob.b).max()
+    res_dual = np.abs(A.T @ y + prob.c).max()
+    assert abs(res_pri - info["res_pri"]) <= 1e-8 * max(1.0, res_pri)
+    assert abs(res_dual - info["res_dual"]) <= 1e-8 * max(1.0, res_dual)
+    assert abs(prob.c @ x - info["pobj"]) <= 1e-8 * max(1.0, abs(info["pobj"]))
+    assert abs(-(prob.b @ y) - info["dobj"]) <= 1e-8 * max(1.0, abs(info["dobj"]))
+    # every iterate returned by SCS is a cone projection: y in K*, s in K, s'y = 0
+    yk = problems.proj_dual_cone_np(y, pr["cone"])
+    assert np.abs(yk - y).max() <= 1e-9 * max(1.0, np.abs(y).max())
+    sk = problems.proj_dual_cone_np(-s, pr["cone"])               # = Proj_{K*}(-s) = 0 iff s in K
+    assert np.abs(sk).max() <= 1e-9 * max(1.0, np.abs(s).max())
+    assert abs(s @ y) <= 1e-9 * max(1.0, np.linalg.norm(s) * np.linalg.norm(y))
+    # determinism of the whole pipeline at scale
+    r2 = capi.solve(lib, prob, verbose=0, acceleration_lookback=0, max_iters=30)
+    r3 = capi.solve(lib, prob, verbose=0, acceleration_lookback=0, max_iters=30)
+    assert np.array_equal(r2["x"], r3["x"]) and r2["info"]["pobj"] == r3["info"]["pobj"]
