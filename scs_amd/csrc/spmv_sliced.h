@@ -129,7 +129,10 @@ struct SlicedDev {
   // worth it only when the gathered vector overflows an XCD's L2 and rows are short
   static bool wanted(int cols, const int *hptr, int rows) {
     if (const char *e = getenv("SCS_AMD_SLICED")) return atoi(e) != 0; // tests force either path
-    if ((size_t)cols * sizeof(real) <= (size_t)3 << 20) return false;
+    // pays off only when x clearly overflows the 4 MB L2 of an XCD (measured: an 8 MB table halves
+    // the gather rate) and there are enough super-blocks to fill 256 CUs
+    if ((size_t)cols * sizeof(real) <= (size_t)6 << 20) return false;
+    if ((long long)hptr[rows] < 4LL * SL_NNZ_SB * 128) return false;
     long long mx = 0;
     for (int r = 0; r < rows; ++r) mx = std::max<long long>(mx, hptr[r + 1] - hptr[r]);
     return mx <= 4 * SL_NNZ_SB;
