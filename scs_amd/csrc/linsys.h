@@ -28,6 +28,7 @@ struct LinSys {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool has_P = false;
+  bool use_fused = false; // whole solve in one workgroup (small systems)
 
   CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector
   CsrDev A;  // CSR(A): m rows, gathers an n-vector

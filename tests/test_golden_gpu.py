@@ -14,8 +14,11 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def test_linsys_boundary_vectors():
-    """(b, s, tol) -> [x; y] captured at the reference's scs_solve_lin_sys boundary."""
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_linsys_boundary_vectors(fused, monkeypatch):
+    """(b, s, tol) -> [x; y] captured at the reference's scs_solve_lin_sys boundary; both
+    the one-workgroup path for small systems and the multi-kernel path."""
+    monkeypatch.setenv("SCS_AMD_FUSED", fused)
     g = np.load(os.path.join(G, "linsys_cfg1.npz"))
     n, m = int(g["n"]), int(g["m"])
     A = sp.csc_matrix((g["Ax_normalized"], g["Ai"], g["Ap"]), shape=(m, n))

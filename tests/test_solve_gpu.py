@@ -96,6 +96,18 @@ def test_default_schedule_same_optimum(n, m, col_nnz, seed, over, q_fixed):
     assert abs(ia["pobj"] - popt) <= 5e-3 * max(1.0, abs(popt))
 
 
+def test_multi_kernel_and_fused_paths_agree(monkeypatch):
+    amd = capi.load("libscsamd.so")
+    pr = problems.random_socp(400, 1200, 8, seed=13)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SCS_AMD_FUSED", flag)
+        res.append(capi.solve(amd, prob, verbose=0, acceleration_lookback=0, cg_tol_override=1e-12))
+    assert res[0]["info"]["iter"] == res[1]["info"]["iter"]
+    assert np.abs(res[0]["x"] - res[1]["x"]).max() <= 1e-7 * max(1.0, np.abs(res[0]["x"]).max())
+
+
 def test_lp_only_and_zero_cone():
     ref = _ref("libscsindir_ref_exactcg.so")
     amd = capi.load("libscsamd.so")
