@@ -124,9 +124,9 @@ typedef struct {
   scs_int ssize;
   scs_int *cs;    /* complex PSD (host fallback absent: rejected)    */
   scs_int cssize;
-  scs_int ep;     /* exponential cones (rejected by this backend)    */
-  scs_int ed;
-  scs_float *p;   /* power cone parameters (rejected by this backend) */
+  scs_int ep;     /* primal exponential cones (3 rows each)          */
+  scs_int ed;     /* dual exponential cones                          */
+  scs_float *p;   /* power cone parameters in [-1,1], <0 = dual cone  */
   scs_int psize;
 } ScsCone;
 

@@ -8,8 +8,7 @@
  * (test/problem_utils.h: _scs_proj_dual_cone, _scs_accum_by_a, _scs_dot, ...) come from
  * the reference's objects.  Unlike test/run_tests.c it does not stop at the first
  * failure and it leaves out the tests that need cones / features this backend
- * announces as out of scope (exponential, power, complex PSD, spectral, problem file
- * I/O) or that poke reference-internal structs.
+ * announces as out of scope (complex PSD, spectral cones, problem file writing) or that poke reference-internal structs.
  */
 #include <stdio.h>
 
@@ -27,6 +26,10 @@
 #include "problems/qafiro_tiny_qp.h"
 #include "problems/small_lp.h"
 #include "problems/small_qp.h"
+#include "problems/test_dual_exp_cone.h"
+#include "problems/test_exp_cone.h"
+#include "problems/test_power_cone.h"
+#include "problems/max_ent.h"
 #include "problems/test_inaccurate.h"
 #include "problems/test_mixed_cones.h"
 #include "problems/test_soc_sizes.h"
@@ -73,6 +76,14 @@ int main(void) {
   RUN(unbounded_tiny_qp);
   RUN(unbounded_lp);
   RUN(unbounded_socp);
+  RUN(test_exp_cone);
+  RUN(test_dual_exp_cone);
+  RUN(test_power_cone);
+  RUN(test_power_cone_p09);
+  RUN(test_dual_power_cone);
+  RUN(test_multi_power);
+  RUN(test_power_cone_infeasible);
+  RUN(max_ent);
   RUN(test_soc_size1);
   RUN(test_soc_size2);
   RUN(test_soc_size3);

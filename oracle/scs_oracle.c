@@ -17,6 +17,9 @@
  * quadratic term), cones zero / nonneg / box / second-order / PSD, Anderson
  * acceleration off (the reference object src/aa.c stays host side and is not
  * restated here).  PSD uses a cyclic Jacobi eigensolver instead of LAPACK dsyevr.
+ * Exponential and power cones (added to the HIP path after the hot path) are
+ * NOT restated: the HIP kernels for them are checked directly against golden vectors
+ * captured from the reference and against the reference's own exp/power test problems.
  */
 #include "scs_oracle.h"
 

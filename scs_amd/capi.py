@@ -237,14 +237,18 @@ def make_cone(cone, T=T64, keep=None):
     k.bsize = int(cone.get("bsize", len(bu) + 1 if len(bu) else 0))
     q = np.ascontiguousarray(cone.get("q", []), dtype=np.int32)
     s = np.ascontiguousarray(cone.get("s", []), dtype=np.int32)
-    holder._cone_arrays = (bu, bl, q, s)
+    pw = np.ascontiguousarray(cone.get("p", []), dtype=f)
+    holder._cone_arrays = (bu, bl, q, s, pw)
     k.bu = bu.ctypes.data_as(T.fp) if len(bu) else None
     k.bl = bl.ctypes.data_as(T.fp) if len(bl) else None
     k.q = q.ctypes.data_as(T.ip) if len(q) else None
     k.qsize = len(q)
     k.s = s.ctypes.data_as(T.ip) if len(s) else None
     k.ssize = len(s)
-    k.cs, k.cssize, k.ep, k.ed, k.p, k.psize = None, 0, 0, 0, None, 0
+    k.cs, k.cssize = None, 0
+    k.ep, k.ed = int(cone.get("ep", 0)), int(cone.get("ed", 0))
+    k.p = pw.ctypes.data_as(T.fp) if len(pw) else None
+    k.psize = len(pw)
     return k
 
 
@@ -253,7 +257,8 @@ def cone_rows(cone):
     q = list(cone.get("q", []))
     s = list(cone.get("s", []))
     bs = cone.get("bsize", len(cone.get("bu", [])) + 1 if len(cone.get("bu", [])) else 0)
-    return int(cone.get("z", 0) + cone.get("l", 0) + bs + sum(q) + sum(v * (v + 1) // 2 for v in s))
+    return int(cone.get("z", 0) + cone.get("l", 0) + bs + sum(q) + sum(v * (v + 1) // 2 for v in s) +
+               3 * (cone.get("ep", 0) + cone.get("ed", 0) + len(cone.get("p", []))))
 
 
 def default_settings(lib, **over):

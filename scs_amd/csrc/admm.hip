@@ -347,7 +347,7 @@ struct SCS_WORK {
   ScsSettings stgs;
   // deep copies (host)
   std::vector<int> cq, cs;
-  std::vector<real> cbu, cbl;
+  std::vector<real> cbu, cbl, cpw;
   ScsCone k;
   HostCsc A, P;
   bool has_P = false;
@@ -596,8 +596,8 @@ static void print_header(const ScsWork *w) {
   printf("------------------------------------------------------------------\n");
   printf("  scs-amd %s : ADMM hot path on MI355X (gfx950), device-resident\n", scs_version());
   printf("  n = %d, m = %d, nnz(A) = %lld%s\n", w->n, w->m, (long long)w->A.p[w->n], w->has_P ? ", P != 0" : "");
-  printf("  cones: z %d, l %d, box %d, soc %d, psd %d | lin-sys: %s\n", w->k.z, w->k.l, w->k.bsize, w->k.qsize,
-         w->k.ssize, scs_get_lin_sys_method());
+  printf("  cones: z %d, l %d, box %d, soc %d, psd %d, exp %d+%d, pow %d | lin-sys: %s\n", w->k.z, w->k.l, w->k.bsize,
+         w->k.qsize, w->k.ssize, w->k.ep, w->k.ed, w->k.psize, scs_get_lin_sys_method());
   printf("  eps_abs %.1e eps_rel %.1e eps_infeas %.1e alpha %.2f scale %.2e (adaptive %d) rho_x %.2e\n",
          (double)w->stgs.eps_abs, (double)w->stgs.eps_rel, (double)w->stgs.eps_infeas, (double)w->stgs.alpha,
          (double)w->stgs.scale, (int)w->stgs.adaptive_scale, (double)w->stgs.rho_x);
@@ -836,7 +836,8 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->k.bu = w->cbu.data();
     w->k.bl = w->cbl.data();
     w->k.cs = nullptr;
-    w->k.p = nullptr;
+    if (k->psize) w->cpw.assign(k->p, k->p + k->psize);
+    w->k.p = w->cpw.data();
     w->A.copy_from(d->A);
     w->has_P = d->P != nullptr;
     if (w->has_P) w->P.copy_from(d->P);

@@ -28,6 +28,9 @@ struct ConeDev {
   int n_psd = 0, psd_kmax = 0;
   DevBuf<int> psd_off, psd_k;
   DevBuf<real> psd_work;    // global scratch for blocks that do not fit in LDS
+  // exponential (primal, dual) and power cones: 3 rows each, after the PSD blocks
+  int ep = 0, ed = 0, psize = 0, exp_off = 0;
+  DevBuf<real> pow_a;       // psize power-cone parameters (negative = dual cone)
   DevBuf<int> status;       // [0] != 0 if any projection failed
 
   // host staging for the B1' boundary
@@ -37,6 +40,7 @@ struct ConeDev {
   // cw (device, length m) <- Proj_K(cw), projection under the diag(r_y)^-1 metric
   // (only the box cone looks at r_y; nullptr = Euclidean).
   void proj_primal(real *cw, const real *r_y);
+  void proj_exp_pow(real *cw);
   // x (device, length m) <- Proj_{K*}^{R}(x) via Moreau; `scratch` is a length-m
   // device buffer that receives the saved input.
   void proj_dual(real *x, real *scratch, const real *r_y);

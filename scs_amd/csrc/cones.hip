@@ -23,6 +23,7 @@
 //              matrix cores (v_mfma_f64_16x16x4_f64) -- replaces LAPACK
 //              dsyevr + dsyrk (cones.c:1028,1052).
 #include "cones.h"
+#include "cones_exp_pow.h"
 #include <algorithm>
 
 namespace scsamd {
@@ -437,8 +438,12 @@ int validate_cone(const ScsCone *k, int m, bool verbose) {
     if (k->s[i] > PSD_K_LIMIT) CONE_FAIL("sd cone larger than 1024 x 1024 not supported by the MI355X backend");
   }
   if (k->cssize > 0) CONE_FAIL("complex PSD cones are not carried by the MI355X backend (out of scope)");
-  if (k->ep > 0 || k->ed > 0) CONE_FAIL("exponential cones are not carried by the MI355X backend (out of scope)");
-  if (k->psize > 0) CONE_FAIL("power cones are not carried by the MI355X backend (out of scope)");
+  if (k->ep < 0) CONE_FAIL("ep cone dimension error");
+  if (k->ed < 0) CONE_FAIL("ed cone dimension error");
+  if (k->psize < 0 || (k->psize > 0 && !k->p)) CONE_FAIL("power cone dimension error");
+  for (int i = 0; i < k->psize; ++i)
+    if (!std::isfinite((double)k->p[i]) || k->p[i] < -1 || k->p[i] > 1)
+      CONE_FAIL("power cone error, values must be finite and in [-1,1]");
   if (cone_total_rows(k) != m) {
     if (verbose)
       printf("cone dimensions %lld not equal to num rows in A = m = %d\n", cone_total_rows(k), m);
@@ -535,6 +540,13 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   up(psd_k, pk);
   if (n_psd && psd_kmax > PSD_LDS_KMAX)
     psd_work.alloc((size_t)n_psd * 2 * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
+  ep = k->ep;
+  ed = k->ed;
+  psize = k->psize;
+  exp_off = off;
+  off += 3 * (ep + ed + psize);
+  pow_a.alloc(psize > 0 ? psize : 1);
+  if (psize > 0) pow_a.upload(k->p, psize, stream);
   status.alloc(1);
   HIP_CHECK(hipStreamSynchronize(stream));
   if (off != m) throw HipError("scs_amd: cone rows do not add up to m");
@@ -568,6 +580,13 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
     hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
                        psd_work.p, psd_kmax, use_lds, status.p);
   }
+  proj_exp_pow(cw);
+}
+
+void ConeDev::proj_exp_pow(real *cw) {
+  if (ep + ed + psize > 0)
+    hipLaunchKernelGGL(k_exp_pow, dim3(small_grid(ep + ed + psize)), dim3(SCSAMD_BLOCK), 0, stream, cw + exp_off, ep, ed,
+                       psize, pow_a.p);
 }
 
 void ConeDev::proj_dual(real *x, real *scratch, const real *r_y) {

@@ -83,6 +83,9 @@ def golden_cones():
         "psd_small": dict(s=[1, 2, 3, 4, 7]),
         "psd_50": dict(s=[50, 50, 33]),
         "mixed": dict(z=2, l=3, bl=[-1.0, -0.5], bu=[0.5, 2.0], q=[3, 20], s=[5, 12]),
+        "exp": dict(ep=40, ed=35),
+        "pow": dict(p=[0.5, 0.3, -0.25, 0.9, -0.7, 0.1, 0.5, -0.5] * 6),
+        "all": dict(z=1, l=2, q=[4], s=[3], ep=5, ed=4, p=[0.4, -0.6, 0.8]),
     }
     out = {}
     meta = {}
@@ -90,6 +93,8 @@ def golden_cones():
         m = capi.cone_rows(cone)
         for variant in ("eucl", "ry"):
             x = rng.uniform(-2, 2, m)
+            if name in ("exp", "pow"):
+                x[: m // 2] *= 10.0 ** rng.uniform(-3, 2, m // 2)   # spread of magnitudes -> all branches
             if "psd_50" == name:
                 x *= rng.uniform(0.1, 10)
             r_y = None
