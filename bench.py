@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--aa", type=int, default=0, help="acceleration_lookback (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-eps", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not sample SpMV launches with HIP events in the timed region (roofline left empty)")
     ap.add_argument("--cpu-sample-n", type=int, default=30000)
     ap.add_argument("--cpu-sample-i0", type=int, default=20)
     ap.add_argument("--cpu-sample-iters", type=int, default=25)
@@ -143,7 +145,8 @@ def main():
     assert it >= 0
     stats0 = T.ScsAmdStats()
     lib.scs_amd_get_stats(w, C.byref(stats0))
-    lib.scs_amd_set_profiling(w, 1)  # samples 1 in 8 SpMV launches with HIP events on OUR stream
+    if not args.no_kernel_timing:
+        lib.scs_amd_set_profiling(w, 1)  # samples 1 in 8 SpMV launches with HIP events on OUR stream
     # ---- timed region: exactly K ADMM iterations --------------------------------
     barrier()
     t0 = time.perf_counter()

@@ -30,6 +30,8 @@
 #include "problems/test_exp_cone.h"
 #include "problems/test_power_cone.h"
 #include "problems/max_ent.h"
+#include "problems/mpc_bug.h"
+#include "problems/random_prob.h"
 #include "problems/test_inaccurate.h"
 #include "problems/test_mixed_cones.h"
 #include "problems/test_soc_sizes.h"
@@ -84,6 +86,8 @@ int main(void) {
   RUN(test_multi_power);
   RUN(test_power_cone_infeasible);
   RUN(max_ent);
+  RUN(mpc_bug);
+  RUN(random_prob);
   RUN(test_soc_size1);
   RUN(test_soc_size2);
   RUN(test_soc_size3);
