@@ -122,7 +122,7 @@ typedef struct {
   scs_int qsize;
   scs_int *s;     /* PSD cone matrix dimensions                      */
   scs_int ssize;
-  scs_int *cs;    /* complex PSD (host fallback absent: rejected)    */
+  scs_int *cs;    /* complex PSD cone matrix dimensions              */
   scs_int cssize;
   scs_int ep;     /* primal exponential cones (3 rows each)          */
   scs_int ed;     /* dual exponential cones                          */

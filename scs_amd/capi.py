@@ -238,14 +238,16 @@ def make_cone(cone, T=T64, keep=None):
     q = np.ascontiguousarray(cone.get("q", []), dtype=np.int32)
     s = np.ascontiguousarray(cone.get("s", []), dtype=np.int32)
     pw = np.ascontiguousarray(cone.get("p", []), dtype=f)
-    holder._cone_arrays = (bu, bl, q, s, pw)
+    cs = np.ascontiguousarray(cone.get("cs", []), dtype=np.int32)
+    holder._cone_arrays = (bu, bl, q, s, pw, cs)
     k.bu = bu.ctypes.data_as(T.fp) if len(bu) else None
     k.bl = bl.ctypes.data_as(T.fp) if len(bl) else None
     k.q = q.ctypes.data_as(T.ip) if len(q) else None
     k.qsize = len(q)
     k.s = s.ctypes.data_as(T.ip) if len(s) else None
     k.ssize = len(s)
-    k.cs, k.cssize = None, 0
+    k.cs = cs.ctypes.data_as(T.ip) if len(cs) else None
+    k.cssize = len(cs)
     k.ep, k.ed = int(cone.get("ep", 0)), int(cone.get("ed", 0))
     k.p = pw.ctypes.data_as(T.fp) if len(pw) else None
     k.psize = len(pw)
@@ -258,6 +260,7 @@ def cone_rows(cone):
     s = list(cone.get("s", []))
     bs = cone.get("bsize", len(cone.get("bu", [])) + 1 if len(cone.get("bu", [])) else 0)
     return int(cone.get("z", 0) + cone.get("l", 0) + bs + sum(q) + sum(v * (v + 1) // 2 for v in s) +
+               sum(int(v) ** 2 for v in cone.get("cs", [])) +
                3 * (cone.get("ep", 0) + cone.get("ed", 0) + len(cone.get("p", []))))
 
 

@@ -346,7 +346,7 @@ struct SCS_WORK {
   int n = 0, m = 0, l = 0, device = 0;
   ScsSettings stgs;
   // deep copies (host)
-  std::vector<int> cq, cs;
+  std::vector<int> cq, cs, ccs;
   std::vector<real> cbu, cbl, cpw;
   ScsCone k;
   HostCsc A, P;
@@ -835,7 +835,8 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->k.s = w->cs.data();
     w->k.bu = w->cbu.data();
     w->k.bl = w->cbl.data();
-    w->k.cs = nullptr;
+    if (k->cssize) w->ccs.assign(k->cs, k->cs + k->cssize);
+    w->k.cs = w->ccs.data();
     if (k->psize) w->cpw.assign(k->p, k->p + k->psize);
     w->k.p = w->cpw.data();
     w->A.copy_from(d->A);

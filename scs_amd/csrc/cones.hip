@@ -248,10 +248,18 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   real *red = reinterpret_cast<real *>(rot_q + PSD_MAX_PAIRS);
   real *lds_mat = red + 8;
   const int cone = blockIdx.x, tid = threadIdx.x;
-  const int k = psd_k[cone];
+  // psd_k > 0: real symmetric block of that order (packed lower triangle).
+  // psd_k < 0: complex Hermitian block of order nn = -psd_k/2 (src/cones.c:1072-1155), handled
+  //            through its real symmetric embedding M = [[A, -B], [B, A]] of order 2 nn
+  //            (H = A + iB): M's eigenvalues are H's, doubled, and the PSD part of M is the
+  //            embedding of the PSD part of H, so the same Jacobi iteration serves both.
+  const int kraw = psd_k[cone];
+  const bool cplx = kraw < 0;
+  const int k = cplx ? -kraw : kraw;
+  const int nn = k / 2; // complex order (cplx only)
   real *X = x + psd_off[cone];
   if (k <= 0) return;
-  if (k == 1) {
+  if (k == 1 || (cplx && nn == 1)) {
     if (tid == 0) X[0] = X[0] > (real)0 ? X[0] : (real)0;
     return;
   }
@@ -269,9 +277,23 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     const int i = e % K2, j = e / K2;
     real v = 0;
     if (i < k && j < k) {
-      const int hi = i > j ? i : j, lo = i > j ? j : i;
-      v = X[packed_index(hi, lo, k)];
-      if (i == j) v *= sqrt2;
+      if (!cplx) {
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        v = X[packed_index(hi, lo, k)];
+        if (i == j) v *= sqrt2;
+      } else {
+        // column c of the packed Hermitian lower triangle starts at c (2 nn - c): real diagonal,
+        // then (re, im) pairs of rows c+1.. (cones.c:1095-1103)
+        const int bi = i / nn, bj = j / nn, ii = i % nn, jj = j % nn;
+        const int r = ii > jj ? ii : jj, c = ii > jj ? jj : ii;
+        if (bi == bj) { // A block: real part, symmetric
+          v = r == c ? X[c * (2 * nn - c)] * sqrt2 : X[c * (2 * nn - c) + 1 + 2 * (r - c - 1)];
+        } else if (r != c) { // +-B block: imaginary part, antisymmetric
+          real im = X[c * (2 * nn - c) + 2 + 2 * (r - c - 1)]; // Im H[r][c], r > c
+          if (ii < jj) im = -im;                                // B[ii][jj] = -B[jj][ii]
+          v = (bi == 1 && bj == 0) ? im : -im;                  // M[i+nn][j] = B, M[i][j+nn] = -B
+        }
+      }
     }
     A[i * ld + j] = v;
     V[i * ld + j] = i == j ? (real)1 : (real)0;
@@ -357,6 +379,28 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   __syncthreads();
   // X+ = W W', lower triangle only, repack with diagonal / sqrt(2)  (cones.c:1052-1063)
   const real inv_sqrt2 = (real)1 / sqrt2;
+  if (cplx) { // Hermitian repack (cones.c:1139-1145): Re = (W W')[r][c], Im = (W W')[r+nn][c]
+    for (int e = tid; e < nn * nn; e += PSD_THREADS) {
+      int c = 0, rem = e;
+      while (rem >= 2 * (nn - c) - 1) {
+        rem -= 2 * (nn - c) - 1;
+        ++c;
+      }
+      int ra, rb = c;
+      real scale = 1;
+      if (rem == 0) {
+        ra = c;
+        scale = inv_sqrt2;
+      } else {
+        const int r = c + 1 + (rem - 1) / 2;
+        ra = ((rem - 1) & 1) ? r + nn : r;
+      }
+      real acc = 0;
+      for (int cidx = 0; cidx < k; ++cidx) acc += V[ra * ld + cidx] * V[rb * ld + cidx];
+      X[e] = acc * scale;
+    }
+    return;
+  }
 #ifndef SFLOAT
   // fp64 matrix cores: D(16x16) += A(16x4) B(4x16), v_mfma_f64_16x16x4_f64.  Lane l holds
   // A[l&15][l>>4], B[l>>4][l&15]; D element (row = (l>>4) + 4*reg, col = l&15), reg 0..3.
@@ -437,7 +481,11 @@ int validate_cone(const ScsCone *k, int m, bool verbose) {
     if (k->s[i] < 0) CONE_FAIL("sd cone dimension error");
     if (k->s[i] > PSD_K_LIMIT) CONE_FAIL("sd cone larger than 1024 x 1024 not supported by the MI355X backend");
   }
-  if (k->cssize > 0) CONE_FAIL("complex PSD cones are not carried by the MI355X backend (out of scope)");
+  if (k->cssize < 0 || (k->cssize > 0 && !k->cs)) CONE_FAIL("complex psd cone dimension error");
+  for (int i = 0; i < k->cssize; ++i) {
+    if (k->cs[i] < 0) CONE_FAIL("complex psd cone dimension error");
+    if (2 * k->cs[i] > PSD_K_LIMIT) CONE_FAIL("complex sd cone larger than 512 x 512 not supported by the MI355X backend");
+  }
   if (k->ep < 0) CONE_FAIL("ep cone dimension error");
   if (k->ed < 0) CONE_FAIL("ed cone dimension error");
   if (k->psize < 0 || (k->psize > 0 && !k->p)) CONE_FAIL("power cone dimension error");
@@ -534,6 +582,12 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
     pk.push_back(k->s[i]);
     psd_kmax = std::max(psd_kmax, k->s[i]);
     off += k->s[i] * (k->s[i] + 1) / 2;
+  }
+  for (int i = 0; i < k->cssize; ++i) { // complex PSD cones follow the real ones (cones.c:1396-1404)
+    poff.push_back(off);
+    pk.push_back(-2 * k->cs[i]);
+    psd_kmax = std::max(psd_kmax, 2 * k->cs[i]);
+    off += k->cs[i] * k->cs[i];
   }
   n_psd = (int)poff.size();
   up(psd_off, poff);

@@ -37,6 +37,7 @@ std::vector<int> cone_segments(const ScsCone *k) {
   b.push_back(k->z + k->l + k->bsize);
   for (int i = 0; i < k->qsize; ++i) b.push_back(k->q[i]);
   for (int i = 0; i < k->ssize; ++i) b.push_back(k->s[i] * (k->s[i] + 1) / 2);
+  for (int i = 0; i < k->cssize; ++i) b.push_back(k->cs[i] * k->cs[i]);
   for (int i = 0; i < k->ep + k->ed + k->psize; ++i) b.push_back(3);
   return b;
 }

@@ -86,6 +86,8 @@ def golden_cones():
         "exp": dict(ep=40, ed=35),
         "pow": dict(p=[0.5, 0.3, -0.25, 0.9, -0.7, 0.1, 0.5, -0.5] * 6),
         "all": dict(z=1, l=2, q=[4], s=[3], ep=5, ed=4, p=[0.4, -0.6, 0.8]),
+        "cpsd": dict(cs=[1, 2, 3, 6, 11]),
+        "all_c": dict(z=1, l=1, q=[3], s=[4], cs=[3, 2], ep=2, ed=1, p=[0.3]),
     }
     out = {}
     meta = {}

@@ -39,7 +39,7 @@ def test_cone_restatement_vs_golden():
     g = np.load(os.path.join(G, "cones.npz"))
     meta = json.load(open(os.path.join(G, "cones_meta.json")))
     for name, cone in meta.items():
-        if cone.get("ep") or cone.get("ed") or cone.get("p"):
+        if cone.get("ep") or cone.get("ed") or cone.get("p") or cone.get("cs"):
             continue  # exp / power cones are outside the restatement's scope (golden-only, GPU tests)
         for variant in ("eucl", "ry"):
             x = g[f"{name}_{variant}_x"]

@@ -54,7 +54,7 @@ def test_cone_dimension_mismatch_and_unsupported_cones(lib):
     prob.k.l += 1                       # rows no longer add up to m
     assert not _init(lib, prob)
     prob = _prob()
-    prob.k.cssize = 1                   # complex PSD cone: out of scope, announced and refused
+    prob.k.cssize = 1                   # complex PSD cone count without its size array
     assert not _init(lib, prob)
     prob = _prob()
     prob.k.ep = 1                       # 3 more rows than A has
