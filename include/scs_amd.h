@@ -261,6 +261,13 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
 /* test hook: every per-iteration linear solve uses this tolerance instead of the
  * schedule of src/scs.c:745-762 (0 restores the schedule) */
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
+/* Problem files in the reference's binary layout (src/rw.c:574-705): replaces
+ * _scs_write_data / _scs_read_data; a file written by either side is read by the other.
+ * `write_data_filename` in ScsSettings makes scs_init write one (src/scs.c:1272-1275).
+ * scs_amd_read_data allocates with malloc; release with scs_amd_free_data. */
+scs_int scs_amd_write_data(const ScsData *d, const ScsCone *k, const ScsSettings *stgs, const char *filename);
+scs_int scs_amd_read_data(const char *filename, ScsData **d, ScsCone **k, ScsSettings **stgs);
+void scs_amd_free_data(ScsData *d, ScsCone *k, ScsSettings *stgs);
 /* Host-side Anderson acceleration, as used inside scs_solve; same contract as the
  * reference's aa_init / aa_apply / aa_safeguard / aa_reset / aa_finish
  * (include/aa.h:66-143).  Pure host code (exposed so it can be tested without a GPU). */

@@ -8,7 +8,7 @@
  * (test/problem_utils.h: _scs_proj_dual_cone, _scs_accum_by_a, _scs_dot, ...) come from
  * the reference's objects.  Unlike test/run_tests.c it does not stop at the first
  * failure and it leaves out the tests that need cones / features this backend
- * announces as out of scope (spectral cones, problem file writing) or that poke reference-internal structs.
+ * announces as out of scope (spectral cones) or that poke reference-internal structs.
  */
 #include <stdio.h>
 
@@ -31,6 +31,8 @@
 #include "problems/test_power_cone.h"
 #include "problems/complex_PSD.h"
 #include "problems/sd_and_complex_sd.h"
+#include "problems/rob_gauss_cov_est.h"
+#include "problems/hs21_tiny_qp_rw.h"
 #include "problems/max_ent.h"
 #include "problems/mpc_bug.h"
 #include "problems/random_prob.h"
@@ -89,6 +91,8 @@ int main(void) {
   RUN(test_power_cone_infeasible);
   RUN(complex_PSD);
   RUN(sd_and_complex_sd);
+  RUN(rob_gauss_cov_est);
+  RUN(hs21_tiny_qp_rw);
   RUN(max_ent);
   RUN(mpc_bug);
   RUN(random_prob);

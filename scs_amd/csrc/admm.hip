@@ -818,8 +818,10 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->device = selected_device();
     const int n = w->n = d->n, m = w->m = d->m, l = w->l = d->n + d->m + 1;
     w->stgs = *stgs;
-    if (stgs->write_data_filename)
-      printf("scs_amd: write_data_filename is not supported by this backend (ignored)\n");
+    if (stgs->write_data_filename) { // src/scs.c:1272-1275
+      printf("Writing raw problem data to %s\n", stgs->write_data_filename);
+      write_problem(d, k, stgs, stgs->write_data_filename);
+    }
     if (stgs->log_csv_filename) printf("scs_amd: log_csv_filename is not supported by this backend (ignored)\n");
     w->stgs.write_data_filename = nullptr;
     w->stgs.log_csv_filename = nullptr;

@@ -35,6 +35,10 @@ void normalize_sol(const Scaling &sc, real *x, real *y, real *s);
 void un_normalize_sol(const Scaling &sc, real *x, real *y, real *s);
 int validate_csc(const ScsMatrix *M, int rows, int cols, bool upper_only, const char *name);
 
+int write_problem(const ScsData *d, const ScsCone *k, const ScsSettings *s, const char *filename);
+int read_problem(const char *filename, ScsData **d, ScsCone **k, ScsSettings **s);
+void free_problem(ScsData *d, ScsCone *k, ScsSettings *s);
+
 // ---- host Anderson acceleration (reference include/aa.h:66-143) --------------
 struct AaHost;
 AaHost *aa_host_init(int dim, int mem, int min_len, int type1, real regularization, real relaxation,
