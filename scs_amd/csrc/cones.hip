@@ -343,7 +343,9 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         const int nblk = npairs * npairs, nv = K2 * npairs;
         for (int e = tid; e < nblk + nv; e += PSD_THREADS) {
           if (e < nblk) {
-            const int P = e / npairs, Q = e % npairs;
+            // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> conflict-free LDS
+            // banks); the column pair is uniform across most of a wave
+            const int Q = e / npairs, P = e % npairs;
             const int p1 = rot_p[P], q1 = rot_q[P], p2 = rot_p[Q], q2 = rot_q[Q];
             const real c1 = rot_c[P], s1 = rot_s[P], c2 = rot_c[Q], s2 = rot_s[Q];
             const real a11 = A[p1 * ld + p2], a12 = A[p1 * ld + q2], a21 = A[q1 * ld + p2], a22 = A[q1 * ld + q2];
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
             A[q1 * ld + p2] = c2 * r21 - s2 * r22;
             A[q1 * ld + q2] = s2 * r21 + c2 * r22;
           } else {
-            const int f = e - nblk, i = f / npairs, Q = f % npairs;
+            const int f = e - nblk, Q = f / K2, i = f % K2; // consecutive rows: stride ld
             const int p2 = rot_p[Q], q2 = rot_q[Q];
             const real c2 = rot_c[Q], s2 = rot_s[Q];
             const real vp = V[i * ld + p2], vq = V[i * ld + q2];
