@@ -280,6 +280,21 @@ scs_int scs_amd_aa_safeguard(scs_float *f_new, scs_float *x_new, void *a);
 void scs_amd_aa_reset(void *a);
 void scs_amd_aa_finish(void *a);
 void scs_amd_aa_get_stats(const void *a, AaStats *out);
+/* Device-resident Anderson acceleration (what scs_solve uses once n+m+1 >= 32768; env
+ * SCS_AMD_AA=host|dev forces either): same contract again, replacing aa_init / aa_apply /
+ * aa_safeguard / aa_reset / aa_finish of include/aa.h:66-143.  These wrappers take HOST
+ * pointers and stage them through HBM so the device path can be pinned against the
+ * reference's AA on identical sequences; inside scs_solve the iterates never leave HBM.
+ * init returns NULL on bad parameters or any HIP failure; apply returns NaN on a HIP failure. */
+void *scs_amd_aa_dev_init(scs_int dim, scs_int mem, scs_int min_len, scs_int type1,
+                          scs_float regularization, scs_float relaxation,
+                          scs_float safeguard_factor, scs_float max_weight_norm,
+                          scs_int ir_max_steps);
+scs_float scs_amd_aa_dev_apply(scs_float *f, const scs_float *x, void *a);
+scs_int scs_amd_aa_dev_safeguard(scs_float *f_new, scs_float *x_new, void *a);
+void scs_amd_aa_dev_reset(void *a);
+void scs_amd_aa_dev_finish(void *a);
+void scs_amd_aa_dev_get_stats(const void *a, AaStats *out);
 /* number of visible HIP devices, or <0 with no usable runtime (never throws) */
 scs_int scs_amd_device_count(void);
 /* select the device used by subsequently created workspaces (default 0) */

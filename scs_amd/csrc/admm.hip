@@ -367,8 +367,9 @@ struct SCS_WORK {
   real sum_log_scale_factor = 0;
   int last_scale_update_iter = 0, n_log_scale_factor = 0, scale_updates = 0;
   int time_limit_reached = 0;
-  // acceleration (host)
+  // acceleration: device-resident for large l, host for small l (see init)
   AaHost *accel = nullptr;
+  AaDev *accel_dev = nullptr;
   std::vector<real> hv, hv_prev;
   real aa_norm = 0;
   int rejected_accel_steps = 0, accepted_accel_steps = 0;
@@ -382,6 +383,7 @@ struct SCS_WORK {
   long long cone_projs = 0;
   ~SCS_WORK() {
     if (accel) aa_host_finish(accel);
+    if (accel_dev) aa_dev_finish(accel_dev);
     if (stream) {
       (void)hipStreamSynchronize(stream);
       (void)hipStreamDestroy(stream); // device buffers are freed by their own destructors
@@ -585,6 +587,8 @@ static int update_scale(ScsWork *w, int iter) { // :1164-1241
     w->ls.set_diag_r_dev(w->diag_r.p);
     update_work_cache(w);
     if (w->accel) aa_host_reset(w->accel);
+  if (w->accel_dev) aa_dev_reset(w->accel_dev);
+    if (w->accel_dev) aa_dev_reset(w->accel_dev);
     hipLaunchKernelGGL(k_remap_v, dim3(glue_grid(w->l)), dim3(SCSAMD_BLOCK), 0, w->stream, w->v.p, w->rsk.p,
                        w->diag_r.p, w->u_t.p, w->u.p, w->l);
   }
@@ -703,6 +707,7 @@ static void finalize(ScsWork *w, ScsSolution *sol, ScsInfo *info, int iter) {
   memset(&info->aa_stats, 0, sizeof info->aa_stats);
   info->aa_stats.last_aa_norm = (real)NAN;
   if (w->accel) aa_host_stats(w->accel, &info->aa_stats);
+  if (w->accel_dev) aa_dev_stats(w->accel_dev, &info->aa_stats);
   info->comp_slack = std::fabs(sty);
   if (info->comp_slack > (real)1e-5 * std::max(nm_s, nm_y))
     printf("WARNING - large complementary slackness residual: %f\n", (double)info->comp_slack);
@@ -882,15 +887,27 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->ls.set_diag_r_dev(w->diag_r.p);
     w->cone.init(&w->k, m, w->stgs.normalize ? w->scal.D.data() : nullptr, w->stream);
     if (w->stgs.acceleration_lookback) {
-      w->accel = aa_host_init(l, w->stgs.acceleration_lookback, w->stgs.acceleration_lookback,
-                              w->stgs.acceleration_type_1, w->stgs.acceleration_regularization,
-                              w->stgs.acceleration_relaxation, (real)1., (real)1e10, 5);
-      if (!w->accel) {
-        if (w->stgs.verbose) printf("WARN: aa_init returned NULL, no acceleration applied.\n");
+      // The O(l mem^2) work of AA runs on the device once l is large enough for the
+      // PCIe round trip of v / v_prev and the host QR to matter; tiny problems keep the
+      // host path (a handful of stream syncs would cost more than the arithmetic).
+      // SCS_AMD_AA=host|dev forces either.
+      bool dev_aa = l >= 32768;
+      if (const char *e = getenv("SCS_AMD_AA")) dev_aa = strcmp(e, "host") != 0;
+      if (dev_aa) {
+        w->accel_dev = aa_dev_init(l, w->stgs.acceleration_lookback, w->stgs.acceleration_lookback,
+                                   w->stgs.acceleration_type_1, w->stgs.acceleration_regularization,
+                                   w->stgs.acceleration_relaxation, (real)1., (real)1e10, 5, w->stream);
       } else {
-        w->hv.resize(l);
-        w->hv_prev.resize(l);
+        w->accel = aa_host_init(l, w->stgs.acceleration_lookback, w->stgs.acceleration_lookback,
+                                w->stgs.acceleration_type_1, w->stgs.acceleration_regularization,
+                                w->stgs.acceleration_relaxation, (real)1., (real)1e10, 5);
+        if (w->accel) {
+          w->hv.resize(l);
+          w->hv_prev.resize(l);
+        }
       }
+      if (!w->accel && !w->accel_dev && w->stgs.verbose)
+        printf("WARN: aa_init returned NULL, no acceleration applied.\n");
     }
     HIP_CHECK(hipStreamSynchronize(w->stream));
   } catch (const std::exception &ex) {
@@ -949,6 +966,7 @@ static void solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) 
   HIP_CHECK(hipMemsetAsync(w->rsk.p, 0, l * sizeof(real), st));
   HIP_CHECK(hipStreamSynchronize(st));
   if (w->accel) aa_host_reset(w->accel);
+  if (w->accel_dev) aa_dev_reset(w->accel_dev);
   update_work_cache(w);
   if (w->stgs.verbose) print_header(w);
 }
@@ -964,7 +982,14 @@ static int solve_steps(ScsWork *w, int upto) {
   int &i = w->cur_iter;
   for (; i < upto && !w->loop_done; ++i) {
     // ---- Anderson acceleration (host) :1359-1366
-    if (w->accel) {
+    if (w->accel_dev) {
+      const double ta = now_ms();
+      if (i > 0 && i % w->stgs.acceleration_interval == 0) {
+        w->aa_norm = aa_dev_apply(w->v.p, w->v_prev.p, w->accel_dev);
+        HIP_CHECK(hipStreamSynchronize(st)); // so that accel_time is the AA's own time
+      }
+      w->t_accel += now_ms() - ta;
+    } else if (w->accel) {
       const double ta = now_ms();
       if (i > 0 && i % w->stgs.acceleration_interval == 0) {
         w->v.download(w->hv.data(), l, st);
@@ -981,7 +1006,7 @@ static int solve_steps(ScsWork *w, int upto) {
     if (do_norm)
       hipLaunchKernelGGL(k_sumsq_partial, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p, l, w->part.p + 8 * PSTRIDE);
     hipLaunchKernelGGL(k_prep_linsys, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p,
-                       w->accel ? w->v_prev.p : (real *)nullptr, w->u_t.p, w->u.p, w->g.p, w->diag_r.p,
+                       (w->accel || w->accel_dev) ? w->v_prev.p : (real *)nullptr, w->u_t.p, w->u.p, w->g.p, w->diag_r.p,
                        w->warm.p, n, l, w->part.p + 8 * PSTRIDE, gl, w->part.p + 9 * PSTRIDE, do_norm);
     // ---- linear system :763 with the tolerance schedule of :745-762
     {
@@ -1037,7 +1062,12 @@ static int solve_steps(ScsWork *w, int upto) {
       hipLaunchKernelGGL(k_dual_update, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->v.p, w->u.p, w->u_t.p, l,
                          w->stgs.alpha);
     // ---- AA safeguard :1439-1447
-    if (w->accel && i % w->stgs.acceleration_interval == 0 && w->aa_norm > 0) {
+    if (w->accel_dev && i % w->stgs.acceleration_interval == 0 && w->aa_norm > 0) {
+      const double ta = now_ms();
+      if (aa_dev_safeguard(w->v.p, w->v_prev.p, w->accel_dev) < 0) w->rejected_accel_steps++;
+      else w->accepted_accel_steps++;
+      w->t_accel += now_ms() - ta;
+    } else if (w->accel && i % w->stgs.acceleration_interval == 0 && w->aa_norm > 0) {
       const double ta = now_ms();
       w->v.download(w->hv.data(), l, st);
       w->v_prev.download(w->hv_prev.data(), l, st);

@@ -49,4 +49,15 @@ void aa_host_reset(AaHost *a);
 void aa_host_finish(AaHost *a);
 void aa_host_stats(const AaHost *a, AaStats *out);
 
+// ---- device Anderson acceleration (aa_dev.hip): same contract, f and x are device
+// pointers and all O(dim) work stays in HBM
+struct AaDev;
+AaDev *aa_dev_init(int dim, int mem, int min_len, int type1, real regularization, real relaxation,
+                   real safeguard_factor, real max_weight_norm, int ir_max_steps, hipStream_t st);
+real aa_dev_apply(real *f, const real *x, AaDev *a);
+int aa_dev_safeguard(real *f_new, real *x_new, AaDev *a);
+void aa_dev_reset(AaDev *a);
+void aa_dev_finish(AaDev *a);
+void aa_dev_stats(const AaDev *a, AaStats *out);
+
 } // namespace scsamd

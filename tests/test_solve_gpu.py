@@ -171,9 +171,12 @@ def test_stepping_api_equals_scs_solve():
     assert np.array_equal(x, r1["x"])  # deterministic reductions: bit-identical reruns
 
 
-def test_anderson_acceleration_on_matches_reference():
+@pytest.mark.parametrize("where", ["host", "dev"])
+def test_anderson_acceleration_on_matches_reference(where, monkeypatch):
     """Default settings (AA type-I, lookback 10).  Host AA is pinned against src/aa.c in
-    tests/test_aa_host.py; here the whole accelerated solve, exact CG on both sides."""
+    tests/test_aa_host.py, the device AA in tests/test_aa_dev_gpu.py; here the whole
+    accelerated solve with either, exact CG on both sides."""
+    monkeypatch.setenv("SCS_AMD_AA", where)
     ref = _ref("libscsindir_ref_exactcg.so")
     amd = capi.load("libscsamd.so")
     pr = problems.random_socp(600, 1800, 12, seed=21)
