@@ -261,6 +261,12 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
 /* test hook: every per-iteration linear solve uses this tolerance instead of the
  * schedule of src/scs.c:745-762 (0 restores the schedule) */
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
+/* Test hook: the data equilibration scs_init performs (linsys/scs_matrix.c:433-496, 25 Ruiz
+ * + 1 L2 pass) on caller-owned CSC arrays.  A->x (and P->x, P may be NULL) are overwritten
+ * with the equilibrated values, D (m) and E (n) receive the scalings.  where = 0: host
+ * code, 1: the device kernels (bit-identical by construction).  0 on success. */
+scs_int scs_amd_equilibrate(ScsMatrix *A, ScsMatrix *P, const ScsCone *k, scs_float *D, scs_float *E,
+                            scs_int where);
 /* Problem files in the reference's binary layout (src/rw.c:574-705): replaces
  * _scs_write_data / _scs_read_data; a file written by either side is read by the other.
  * `write_data_filename` in ScsSettings makes scs_init write one (src/scs.c:1272-1275).

@@ -846,18 +846,32 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->k.cs = w->ccs.data();
     if (k->psize) w->cpw.assign(k->p, k->p + k->psize);
     w->k.p = w->cpw.data();
+    const bool dbg = getenv("SCS_AMD_DEBUG") != nullptr;
+    double tp = now_ms();
+    auto phase = [&](const char *what) {
+      if (dbg) fprintf(stderr, "[scs_amd init] %-22s %8.1f ms\n", what, now_ms() - tp);
+      tp = now_ms();
+    };
     w->A.copy_from(d->A);
     w->has_P = d->P != nullptr;
     if (w->has_P) w->P.copy_from(d->P);
     HIP_CHECK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+    phase("copy + stream");
     // equilibrate on the host copy (normalize_a_p) or identity scaling
+    CsrPattern a_pattern; // filled by the device equilibration, reused by the linsys init
     if (w->stgs.normalize) {
-      equilibrate(w->has_P ? &w->P : nullptr, w->A, &w->k, w->scal);
+      // 26 streaming passes over nnz: on the device once the matrix is big enough for
+      // the ~200 launches to be cheaper than the host loops (SCS_AMD_EQUIL=host|dev forces)
+      bool dev_eq = (long long)d->A->p[n] >= 100000;
+      if (const char *e = getenv("SCS_AMD_EQUIL")) dev_eq = strcmp(e, "host") != 0;
+      if (dev_eq) equilibrate_dev(w->has_P ? &w->P : nullptr, w->A, &w->k, w->scal, w->stream, &a_pattern);
+      else equilibrate(w->has_P ? &w->P : nullptr, w->A, &w->k, w->scal);
     } else {
       w->scal.D.assign(m, (real)1);
       w->scal.E.assign(n, (real)1);
       w->scal.primal_scale = w->scal.dual_scale = 1;
     }
+    phase("equilibrate");
     // device vectors
     for (DevBuf<real> *v : {&w->u, &w->u_t, &w->v, &w->v_prev, &w->rsk, &w->diag_r}) v->alloc(l);
     w->g.alloc(l - 1);
@@ -879,10 +893,13 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->c_orig.assign(d->c, d->c + n);
     HIP_CHECK(hipStreamSynchronize(w->stream));
     if (scs_update(w, w->b_orig.data(), w->c_orig.data()) != 0) throw HipError("scs_amd: scs_update failed");
+    phase("vectors + b,c");
     // linear system + cones on the device
     ScsMatrix Av = w->A.view(), Pv;
     if (w->has_P) Pv = w->P.view();
-    w->ls.init(&Av, w->has_P ? &Pv : nullptr, w->stream);
+    w->ls.init(&Av, w->has_P ? &Pv : nullptr, w->stream, &a_pattern);
+    a_pattern = CsrPattern();
+    phase("linsys init");
     set_diag_r(w);
     w->ls.set_diag_r_dev(w->diag_r.p);
     w->cone.init(&w->k, m, w->stgs.normalize ? w->scal.D.data() : nullptr, w->stream);
@@ -1177,6 +1194,40 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info) {
 // test hook: force every per-iteration linear solve to this tolerance (0 = schedule)
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol) {
   if (w) w->cg_tol_override = tol;
+}
+
+// test hook: the equilibration of scs_init on caller-owned arrays, host or device
+scs_int scs_amd_equilibrate(ScsMatrix *A, ScsMatrix *P, const ScsCone *k, scs_float *D, scs_float *E,
+                            scs_int where) {
+  try {
+    HostCsc a, p;
+    a.copy_from(A);
+    if (P) p.copy_from(P);
+    Scaling sc;
+    if (where) {
+      if (scs_amd_device_count() <= 0) throw HipError("scs_amd: no HIP device visible");
+      HIP_CHECK(hipSetDevice(selected_device()));
+      hipStream_t st;
+      HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      try {
+        equilibrate_dev(P ? &p : nullptr, a, k, sc, st, nullptr);
+      } catch (...) {
+        (void)hipStreamDestroy(st);
+        throw;
+      }
+      (void)hipStreamDestroy(st);
+    } else {
+      equilibrate(P ? &p : nullptr, a, k, sc);
+    }
+    memcpy(A->x, a.x.data(), a.x.size() * sizeof(real));
+    if (P) memcpy(P->x, p.x.data(), p.x.size() * sizeof(real));
+    memcpy(D, sc.D.data(), sc.D.size() * sizeof(real));
+    memcpy(E, sc.E.data(), sc.E.size() * sizeof(real));
+    return 0;
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
 }
 
 void scs_finish(ScsWork *w) { delete w; }

@@ -4,6 +4,7 @@
 // every vector in HBM and the loop controlled from the device.
 #pragma once
 #include "spmv.h"
+#include "scs_host.h"
 #include "spmv_sliced.h"
 
 namespace scsamd {
@@ -57,7 +58,8 @@ struct LinSys {
   LinSys(const LinSys &) = delete;
 
   // A, P: host CSC as handed over by the reference (normalized data).
-  void init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s);
+  // `pat` (optional): an already-built pattern transpose of A_csc
+  void init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s, const CsrPattern *pat = nullptr);
   // diag_r = [R_x (n); R_y (m)] : host or device source
   void set_diag_r_host(const real *diag_r);
   void set_diag_r_dev(const real *diag_r_dev);

@@ -443,7 +443,7 @@ static void host_transpose(int rows_out, int cols_out, const int *Ap, const int 
     }
 }
 
-void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s) {
+void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s, const CsrPattern *pat) {
   n = A_csc->n;
   m = A_csc->m;
   if (s) {
@@ -453,20 +453,44 @@ void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s)
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
   }
+  const bool dbg_t = getenv("SCS_AMD_DEBUG") != nullptr;
+  auto t_now = [] {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  };
+  double tp = t_now();
+  auto phase = [&](const char *what) {
+    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] %-18s %8.1f ms\n", what, t_now() - tp);
+    tp = t_now();
+  };
   // CSC(A) is CSR(A'): upload as is
   At.upload(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+  phase("upload At");
   if (SlicedDev::wanted(m, A_csc->p, n)) {
     At.sliced = new SlicedDev();
     At.sliced->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+    phase("sliced At");
   }
   {
-    std::vector<int> Cp, Ci;
+    std::vector<int> Cp_own, Ci_own;
     std::vector<real> Cx;
-    host_transpose(m, n, A_csc->p, A_csc->i, A_csc->x, Cp, Ci, Cx);
+    if (pat && !pat->empty()) { // values follow the cached pattern: a gather, not a sort
+      const size_t nz = (size_t)A_csc->p[n];
+      Cx.resize(nz);
+      for (size_t q = 0; q < nz; ++q) Cx[q] = A_csc->x[pat->pos[q]];
+    } else {
+      host_transpose(m, n, A_csc->p, A_csc->i, A_csc->x, Cp_own, Ci_own, Cx);
+    }
+    const std::vector<int> &Cp = (pat && !pat->empty()) ? pat->rp : Cp_own;
+    const std::vector<int> &Ci = (pat && !pat->empty()) ? pat->rj : Ci_own;
+    phase("transpose");
     A.upload(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
+    phase("upload A");
     if (SlicedDev::wanted(n, Cp.data(), m)) {
       A.sliced = new SlicedDev();
       A.sliced->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
+      phase("sliced A");
     }
   }
   has_P = P_csc != nullptr;

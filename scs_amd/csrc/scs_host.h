@@ -28,8 +28,18 @@ struct Scaling {
   real primal_scale = 1, dual_scale = 1;
 };
 
+// pattern of the CSR copy of a CSC matrix: row pointers, column indices and, for every
+// CSR entry, its position in the CSC arrays (so values can be gathered, never re-sorted)
+struct CsrPattern {
+  std::vector<int> rp, rj, pos;
+  bool empty() const { return rp.empty(); }
+};
+
 std::vector<int> cone_segments(const ScsCone *k);
 void equilibrate(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc);
+// the same passes on the device (equilibrate_dev.hip); bit-identical results
+void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipStream_t st,
+                     CsrPattern *csr_cache);
 void normalize_b_c(Scaling &sc, real *b, real *c);
 void normalize_sol(const Scaling &sc, real *x, real *y, real *s);
 void un_normalize_sol(const Scaling &sc, real *x, real *y, real *s);
