@@ -377,11 +377,16 @@ struct SCS_WORK {
   int cur_iter = 0, run_status = SCS_UNFINISHED;
   bool loop_done = false, stepped = false;
   double t_solve0 = 0, t_lin = 0, t_accel = 0, cg_tol_override = 0;
+  // per-iteration CSV log (src/rw.c:686-863): diagnostic, computed on the host
+  std::string log_csv_name;
+  FILE *log_csv_fout = nullptr;
+  std::vector<real> lg; // staging for the vectors the log takes norms of
   // instrumentation
   EventTimer cone_timer;
   bool profiling = false;
   long long cone_projs = 0;
   ~SCS_WORK() {
+    if (log_csv_fout) fclose(log_csv_fout);
     if (accel) aa_host_finish(accel);
     if (accel_dev) aa_dev_finish(accel_dev);
     if (stream) {
@@ -542,6 +547,161 @@ static void populate_residuals(ScsWork *w, int iter) {
     o = r;
   }
 }
+
+// ---- per-iteration CSV log: column set, order and formats of src/rw.c:707-863 ----------
+// A diagnostic (the reference recomputes all residuals every iteration when it is on),
+// so the ~30 extra vector norms are taken on the host from downloaded copies instead of
+// growing the hot-path kernels.  The header carries the five spectral column names the
+// reference emits in its default (LAPACK) build although the rows never fill them.
+static real h_norm_inf(const real *v, size_t len) {
+  real a = 0;
+  for (size_t i = 0; i < len; ++i) a = std::max(a, (real)std::fabs(v[i]));
+  return a;
+}
+static real h_norm_2(const real *v, size_t len) {
+  real a = 0;
+  for (size_t i = 0; i < len; ++i) a += v[i] * v[i];
+  return std::sqrt(a);
+}
+static void log_csv_row(ScsWork *w, int iter) {
+  FILE *fout = w->log_csv_fout;
+  if (!fout) return;
+  populate_residuals(w, iter);
+  const size_t n = (size_t)w->n, m = (size_t)w->m, l = (size_t)w->l;
+  hipStream_t st = w->stream;
+  // staging layout: u | u_t | v | v_prev | rsk | ax | aty | px | 6 work vectors
+  w->lg.resize(5 * l + m + 2 * n + 3 * m + 3 * n);
+  real *u = w->lg.data(), *u_t = u + l, *v = u_t + l, *v_prev = v + l, *rsk = v_prev + l, *ax = rsk + l,
+       *aty = ax + m, *px = aty + n, *wm0 = px + n, *wm1 = wm0 + m, *wm2 = wm1 + m, *wn0 = wm2 + m, *wn1 = wn0 + n,
+       *wn2 = wn1 + n;
+  w->u.download(u, l, st);
+  w->u_t.download(u_t, l, st);
+  w->v.download(v, l, st);
+  w->v_prev.download(v_prev, l, st);
+  w->rsk.download(rsk, l, st);
+  w->ax.download(ax, m, st);
+  w->aty.download(aty, n, st);
+  if (w->has_P) w->px.download(px, n, st);
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (!w->has_P) std::fill(px, px + n, (real)0);
+  const Resid &r = w->r_o, &rn = w->r_n;
+  const real *xn = u, *yn = u + n, *sn = rsk + n;
+  const bool nrm = w->stgs.normalize != 0;
+  const real ds = w->scal.dual_scale, ps = w->scal.primal_scale;
+  fprintf(fout, "%li,", (long)iter);
+  fprintf(fout, "%.16e,", (double)r.res_pri);
+  fprintf(fout, "%.16e,", (double)r.res_dual);
+  fprintf(fout, "%.16e,", (double)r.gap);
+  { // un-normalised iterate (src/normalize.c:78-91)
+    for (size_t j = 0; j < n; ++j) wn0[j] = nrm ? xn[j] * (w->scal.E[j] / ds) : xn[j];
+    for (size_t i = 0; i < m; ++i) {
+      wm0[i] = nrm ? yn[i] * (w->scal.D[i] / ps) : yn[i];
+      wm1[i] = nrm ? sn[i] / (w->scal.D[i] * ds) : sn[i];
+    }
+    fprintf(fout, "%.16e,", (double)h_norm_inf(wn0, n));
+    fprintf(fout, "%.16e,", (double)h_norm_inf(wm0, m));
+    fprintf(fout, "%.16e,", (double)h_norm_inf(wm1, m));
+    fprintf(fout, "%.16e,", (double)h_norm_2(wn0, n));
+    fprintf(fout, "%.16e,", (double)h_norm_2(wm0, m));
+    fprintf(fout, "%.16e,", (double)h_norm_2(wm1, m));
+  }
+  fprintf(fout, "%.16e,", (double)h_norm_inf(xn, n));
+  fprintf(fout, "%.16e,", (double)h_norm_inf(yn, m));
+  fprintf(fout, "%.16e,", (double)h_norm_inf(sn, m));
+  fprintf(fout, "%.16e,", (double)h_norm_2(xn, n));
+  fprintf(fout, "%.16e,", (double)h_norm_2(yn, m));
+  fprintf(fout, "%.16e,", (double)h_norm_2(sn, m));
+  // residual vectors, normalised (wm2 / wn2) and original (wm0.. / wn0..)
+  const real inv_ds = (real)1.0 / ds, inv_ps = (real)1.0 / ps;
+  for (size_t i = 0; i < m; ++i) {
+    const real axs = ax[i] + sn[i];
+    wm2[i] = axs - rn.tau * w->b_nrm[i];
+    const real f = nrm ? inv_ds / w->scal.D[i] : (real)1;
+    wm0[i] = wm2[i] * f; // ax_s_btau
+    wm1[i] = axs * f;    // ax_s
+  }
+  for (size_t j = 0; j < n; ++j) {
+    wn2[j] = px[j] + aty[j] + rn.tau * w->c_nrm[j];
+    const real f = nrm ? inv_ps / w->scal.E[j] : (real)1;
+    wn0[j] = wn2[j] * f; // px_aty_ctau
+  }
+  fprintf(fout, "%.16e,", (double)h_norm_inf(wm0, m));
+  fprintf(fout, "%.16e,", (double)h_norm_inf(wn0, n));
+  fprintf(fout, "%.16e,", (double)h_norm_2(wm0, m));
+  fprintf(fout, "%.16e,", (double)h_norm_2(wn0, n));
+  fprintf(fout, "%.16e,", (double)r.res_infeas);
+  fprintf(fout, "%.16e,", (double)r.res_unbdd_a);
+  fprintf(fout, "%.16e,", (double)r.res_unbdd_p);
+  fprintf(fout, "%.16e,", (double)r.pobj);
+  fprintf(fout, "%.16e,", (double)r.dobj);
+  fprintf(fout, "%.16e,", (double)r.tau);
+  fprintf(fout, "%.16e,", (double)r.kap);
+  fprintf(fout, "%.16e,", (double)rn.res_pri);
+  fprintf(fout, "%.16e,", (double)rn.res_dual);
+  fprintf(fout, "%.16e,", (double)rn.gap);
+  fprintf(fout, "%.16e,", (double)h_norm_inf(wm2, m));
+  fprintf(fout, "%.16e,", (double)h_norm_inf(wn2, n));
+  fprintf(fout, "%.16e,", (double)h_norm_2(wm2, m));
+  fprintf(fout, "%.16e,", (double)h_norm_2(wn2, n));
+  fprintf(fout, "%.16e,", (double)rn.res_infeas);
+  fprintf(fout, "%.16e,", (double)rn.res_unbdd_a);
+  fprintf(fout, "%.16e,", (double)rn.res_unbdd_p);
+  fprintf(fout, "%.16e,", (double)rn.pobj);
+  fprintf(fout, "%.16e,", (double)rn.dobj);
+  fprintf(fout, "%.16e,", (double)rn.tau);
+  fprintf(fout, "%.16e,", (double)rn.kap);
+  { // ax, ax_s, px, aty of the original problem
+    for (size_t i = 0; i < m; ++i) wm2[i] = ax[i] * (nrm ? inv_ds / w->scal.D[i] : (real)1);
+    fprintf(fout, "%.16e,", (double)h_norm_inf(wm2, m));
+    fprintf(fout, "%.16e,", (double)h_norm_inf(wm1, m));
+    for (size_t j = 0; j < n; ++j) {
+      const real f = nrm ? inv_ps / w->scal.E[j] : (real)1;
+      wn1[j] = px[j] * f;
+      wn2[j] = aty[j] * f;
+    }
+    fprintf(fout, "%.16e,", (double)h_norm_inf(wn1, n));
+    fprintf(fout, "%.16e,", (double)h_norm_inf(wn2, n));
+  }
+  fprintf(fout, "%.16e,", (double)r.xt_p_x);
+  fprintf(fout, "%.16e,", (double)r.xt_p_x_tau);
+  fprintf(fout, "%.16e,", (double)r.ctx);
+  fprintf(fout, "%.16e,", (double)r.ctx_tau);
+  fprintf(fout, "%.16e,", (double)r.bty);
+  fprintf(fout, "%.16e,", (double)r.bty_tau);
+  fprintf(fout, "%.16e,", (double)h_norm_inf(w->b_orig.data(), m));
+  fprintf(fout, "%.16e,", (double)h_norm_inf(w->c_orig.data(), n));
+  fprintf(fout, "%.16e,", (double)w->stgs.scale);
+  {
+    real d2u = 0, d2v = 0, diu = 0, div = 0;
+    for (size_t i = 0; i < l; ++i) {
+      const real a = u[i] - u_t[i], b = v[i] - v_prev[i];
+      d2u += a * a;
+      d2v += b * b;
+      diu = std::max(diu, (real)std::fabs(a));
+      div = std::max(div, (real)std::fabs(b));
+    }
+    fprintf(fout, "%.16e,", (double)std::sqrt(d2u));
+    fprintf(fout, "%.16e,", (double)std::sqrt(d2v));
+    fprintf(fout, "%.16e,", (double)diu);
+    fprintf(fout, "%.16e,", (double)div);
+  }
+  fprintf(fout, "%.16e,", (double)w->aa_norm);
+  fprintf(fout, "%li,", (long)w->accepted_accel_steps);
+  fprintf(fout, "%li,", (long)w->rejected_accel_steps);
+  fprintf(fout, "%.16e,", (now_ms() - w->t_solve0) / 1e3);
+  fprintf(fout, "\n");
+}
+static const char *LOG_CSV_HEADER =
+    "iter,res_pri,res_dual,gap,x_nrm_inf,y_nrm_inf,s_nrm_inf,x_nrm_2,y_nrm_2,s_nrm_2,x_nrm_inf_normalized,"
+    "y_nrm_inf_normalized,s_nrm_inf_normalized,x_nrm_2_normalized,y_nrm_2_normalized,s_nrm_2_normalized,"
+    "ax_s_btau_nrm_inf,px_aty_ctau_nrm_inf,ax_s_btau_nrm_2,px_aty_ctau_nrm_2,res_infeas,res_unbdd_a,res_unbdd_p,"
+    "pobj,dobj,tau,kap,res_pri_normalized,res_dual_normalized,gap_normalized,ax_s_btau_nrm_inf_normalized,"
+    "px_aty_ctau_nrm_inf_normalized,ax_s_btau_nrm_2_normalized,px_aty_ctau_nrm_2_normalized,res_infeas_normalized,"
+    "res_unbdd_a_normalized,res_unbdd_p_normalized,pobj_normalized,dobj_normalized,tau_normalized,kap_normalized,"
+    "ax_nrm_inf,ax_s_nrm_inf,px_nrm_inf,aty_nrm_inf,xt_p_x,xt_p_x_tau,ctx,ctx_tau,bty,bty_tau,b_nrm_inf,c_nrm_inf,"
+    "scale,diff_u_ut_nrm_2,diff_v_v_prev_nrm_2,diff_u_ut_nrm_inf,diff_v_v_prev_nrm_inf,aa_norm,"
+    "accepted_accel_steps,rejected_accel_steps,time,spectral_Newton_iter,plain_Newton_success,res_dual_spectral,"
+    "res_pri_spectral,comp_spectral,\n";
 
 static int has_converged(ScsWork *w) { // :611-649
   const Resid &r = w->r_o;
@@ -827,7 +987,10 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
       printf("Writing raw problem data to %s\n", stgs->write_data_filename);
       write_problem(d, k, stgs, stgs->write_data_filename);
     }
-    if (stgs->log_csv_filename) printf("scs_amd: log_csv_filename is not supported by this backend (ignored)\n");
+    if (stgs->log_csv_filename) { // src/scs.c:1275-1278
+      printf("Logging run data to %s\n", stgs->log_csv_filename);
+      w->log_csv_name = stgs->log_csv_filename;
+    }
     w->stgs.write_data_filename = nullptr;
     w->stgs.log_csv_filename = nullptr;
     // deep copies
@@ -962,6 +1125,12 @@ static void solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) 
   w->aa_norm = 0;
   w->r_n = Resid();
   w->r_o = Resid();
+  if (!w->log_csv_name.empty()) { // open_csv_log_file, src/rw.c:686-698 (rewritten by every solve)
+    if (w->log_csv_fout) fclose(w->log_csv_fout);
+    w->log_csv_fout = fopen(w->log_csv_name.c_str(), "w");
+    if (!w->log_csv_fout) printf("Error: Could not open %s for writing\n", w->log_csv_name.c_str());
+    else fputs(LOG_CSV_HEADER, w->log_csv_fout);
+  }
   // warm / cold start (:660-687)
   std::vector<real> hv(l, (real)0);
   if (warm_start && sol && sol->x && sol->y && sol->s) {
@@ -1099,6 +1268,9 @@ static int solve_steps(ScsWork *w, int upto) {
       }
       w->t_accel += now_ms() - ta;
     }
+    // log after the scale update so that the residual recomputation does not change the
+    // algorithm's own cadence more than the reference's does (:1449-1454)
+    if (w->log_csv_fout) log_csv_row(w, i);
   }
   return 0;
 }
@@ -1108,6 +1280,11 @@ static void solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info) {
   HIP_CHECK(hipSetDevice(w->device));
   strcpy(info->lin_sys_solver, scs_get_lin_sys_method());
   info->status_val = w->run_status;
+  if (w->log_csv_fout) { // final row + close (:1457-1461, :1481)
+    log_csv_row(w, i);
+    fclose(w->log_csv_fout);
+    w->log_csv_fout = nullptr;
+  }
   if (w->stgs.verbose) {
     populate_residuals(w, i);
     print_summary(w, i, w->t_solve0);
