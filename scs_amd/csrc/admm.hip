@@ -20,6 +20,8 @@
 #include "linsys.h"
 #include "cones.h"
 #include "scs_host.h"
+#include <csignal>
+#include <mutex>
 #include <chrono>
 #include <algorithm>
 
@@ -880,6 +882,36 @@ static void finalize(ScsWork *w, ScsSolution *sol, ScsInfo *info, int iter) {
   }
 }
 
+// ---- ctrl-c support (behaviour of src/ctrlc.c:84-125): while at least one solve is in
+// flight SIGINT sets a flag instead of killing the process; the loop polls it at the
+// convergence cadence and returns SCS_SIGINT.  Counted, so concurrent solves on several
+// threads install / restore the previous handler exactly once.
+namespace {
+volatile sig_atomic_t g_sigint_seen = 0;
+struct sigaction g_sigint_prev;
+std::mutex g_sigint_mu;
+int g_sigint_listeners = 0;
+static void on_sigint(int sig) { g_sigint_seen = sig ? sig : -1; }
+struct InterruptListener { // RAII: every exit path of scs_solve restores the handler
+  InterruptListener() {
+    std::lock_guard<std::mutex> lk(g_sigint_mu);
+    if (g_sigint_listeners++ == 0) {
+      g_sigint_seen = 0;
+      struct sigaction act;
+      memset(&act, 0, sizeof act);
+      sigemptyset(&act.sa_mask);
+      act.sa_handler = on_sigint;
+      sigaction(SIGINT, &act, &g_sigint_prev);
+    }
+  }
+  ~InterruptListener() {
+    std::lock_guard<std::mutex> lk(g_sigint_mu);
+    if (g_sigint_listeners > 0 && --g_sigint_listeners == 0) sigaction(SIGINT, &g_sigint_prev, nullptr);
+  }
+};
+inline bool interrupted() { return g_sigint_seen != 0; }
+} // namespace
+
 static scs_int fail_out(ScsWork *w, int m, int n, ScsSolution *sol, ScsInfo *info, scs_int status,
                         const char *msg, const char *ststr) { // :321-371
   if (info) {
@@ -1226,6 +1258,7 @@ static int solve_steps(ScsWork *w, int upto) {
     hipLaunchKernelGGL(k_post_cone, dim3(gl), dim3(SCSAMD_BLOCK), 0, st, w->u.p, w->u_t.p, w->v.p, w->rsk.p,
                        w->diag_r.p, w->cw.p, n, l, fuse_dual ? w->stgs.alpha : (real)0);
     if (check) {
+      if (interrupted()) return -2; // :1400-1403
       populate_residuals(w, i);
       if ((w->run_status = has_converged(w)) != 0) {
         w->loop_done = true;
@@ -1316,10 +1349,19 @@ scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_star
     printf("ERROR: missing ScsWork, ScsSolution or ScsInfo input\n");
     return SCS_FAILED;
   }
+  InterruptListener listener; // :1344, restored on every return below (:369, :1482)
   try {
     solve_begin(w, sol, warm_start);
-    if (solve_steps(w, w->stgs.max_iters) < 0)
+    const int rc = solve_steps(w, w->stgs.max_iters);
+    if (rc < 0) {
+      if (w->log_csv_fout) {
+        fclose(w->log_csv_fout);
+        w->log_csv_fout = nullptr;
+      }
+      HIP_CHECK(hipStreamSynchronize(w->stream));
+      if (rc == -2) return fail_out(w, w->m, w->n, sol, info, SCS_SIGINT, "interrupted", "interrupted");
       return fail_out(w, w->m, w->n, sol, info, SCS_FAILED, "error in update_scale", "failure");
+    }
     solve_end(w, sol, info);
   } catch (const std::exception &ex) {
     fprintf(stderr, "%s\n", ex.what());

@@ -210,3 +210,28 @@ def test_sdp_with_box_exact_cg_parity():
     assert ia["iter"] == ir["iter"]
     for k in ("pobj", "dobj", "res_pri", "res_dual", "gap"):
         assert _rel(ia[k], ir[k], floor=1e-3) <= REL, (k, ia[k], ir[k])
+
+
+def test_sigint_during_solve_returns_scs_sigint():
+    """src/ctrlc.c + src/scs.c:1400-1403: SIGINT while solving -> status SCS_SIGINT (-5), NaN-filled
+    solution, and the previous handler is back afterwards."""
+    import os
+    import signal
+    import threading
+
+    amd = capi.load("libscsamd.so")
+    pr = problems.random_socp(20000, 40000, 10, seed=4)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    before = signal.getsignal(signal.SIGINT)
+    t = threading.Timer(0.4, lambda: os.kill(os.getpid(), signal.SIGINT))
+    t.start()
+    try:
+        r = capi.solve(amd, prob, verbose=0, eps_abs=1e-14, eps_rel=1e-14, max_iters=200000, acceleration_lookback=0)
+    finally:
+        t.cancel()
+    assert r["info"]["status_val"] == -5 and r["info"]["status"] == "interrupted"
+    assert r["info"]["iter"] == -1 and np.all(np.isnan(r["x"])) and np.all(np.isnan(r["s"]))
+    assert signal.getsignal(signal.SIGINT) == before
+    # and the library is usable afterwards
+    r2 = capi.solve(amd, prob, verbose=0, max_iters=50)
+    assert r2["info"]["status_val"] in (1, 2)
