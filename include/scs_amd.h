@@ -261,6 +261,35 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
 /* test hook: every per-iteration linear solve uses this tolerance instead of the
  * schedule of src/scs.c:745-762 (0 restores the schedule) */
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
+/* ---- B1', drop-in form: the reference's internal cone interface -------------------
+ * The nine symbols of include/cones.h:80-90 (prefix `_scs_` = glbopts.h's SCS(x)), exported
+ * by libscsamd_cones.so so that a reference build links it IN PLACE OF src/cones.o (the
+ * reference has no plugin API for cones).  Same argument meaning and return conventions:
+ * init returns NULL on failure, proj_dual_cone returns <0 on failure (the reference then
+ * aborts with SCS_FAILED, src/scs.c:1389), deep_copy_cone returns 1 on success,
+ * get_cone_header returns a malloc'd string the caller frees.  Vectors are HOST pointers
+ * (x of length m is projected in place).  `struct SCS_CONE_WORK` is opaque here; the
+ * reference only looks inside it under USE_SPECTRAL_CONES, which this backend does not
+ * carry.  The device side is created at the first projection (that is when the caller says,
+ * through `scal`, whether box bounds are normalised by D: src/cones.c:1557-1565). */
+typedef struct SCS_CONE_WORK ScsConeWork;
+typedef struct { /* reference include/scs_work.h:24-29 */
+  scs_float *D, *E;
+  scs_int m, n;
+  scs_float primal_scale, dual_scale;
+} ScsScaling;
+ScsConeWork *_scs_init_cone(ScsCone *k, scs_int m);                      /* src/cones.c:1498 */
+scs_int _scs_proj_dual_cone(scs_float *x, ScsConeWork *c, const ScsScaling *scal,
+                            scs_float *r_y);                             /* src/cones.c:1552 */
+void _scs_finish_cone(ScsConeWork *c);                                   /* src/cones.c:284  */
+void _scs_set_r_y(const ScsConeWork *c, scs_float scale, scs_float *r_y);/* src/cones.c:349  */
+void _scs_enforce_cone_boundaries(const ScsConeWork *c, scs_float *vec,
+                                  scs_float (*f)(const scs_float *, scs_int)); /* :366 */
+scs_int _scs_validate_cones(const ScsData *d, const ScsCone *k);         /* src/cones.c:583  */
+char *_scs_get_cone_header(const ScsCone *k);                            /* src/cones.c:565  */
+scs_int _scs_deep_copy_cone(ScsCone *dest, const ScsCone *src);          /* src/cones.c:154  */
+void _scs_free_cone(ScsCone *k);                                         /* src/cones.c:122  */
+
 /* Test hook: the data equilibration scs_init performs (linsys/scs_matrix.c:433-496, 25 Ruiz
  * + 1 L2 pass) on caller-owned CSC arrays.  A->x (and P->x, P may be NULL) are overwritten
  * with the equilibrated values, D (m) and E (n) receive the scalings.  where = 0: host

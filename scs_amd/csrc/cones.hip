@@ -473,8 +473,14 @@ int validate_cone(const ScsCone *k, int m, bool verbose) {
   if (k->l < 0) CONE_FAIL("lp cone dimension error");
   if (k->bsize < 0) CONE_FAIL("box cone dimension error");
   if (k->bsize > 1 && (!k->bl || !k->bu)) CONE_FAIL("box cone bounds missing");
-  for (int i = 0; i < k->bsize - 1; ++i)
+  for (int i = 0; i < k->bsize - 1; ++i) {
+    // NaN bounds, and infinities pointing the wrong way (bl = +inf / bu = -inf), are errors;
+    // bl = -inf and bu = +inf are the valid one-sided cases
+    if (k->bl[i] != k->bl[i] || k->bu[i] != k->bu[i]) CONE_FAIL("box cone error, bounds must not be NaN");
+    if (k->bl[i] == (real)INFINITY || k->bu[i] == (real)-INFINITY)
+      CONE_FAIL("box cone error, infinite bound in the wrong direction");
     if (k->bl[i] > k->bu[i]) CONE_FAIL("infeasible: box lower bound larger than upper bound");
+  }
   if (k->qsize < 0 || (k->qsize > 0 && !k->q)) CONE_FAIL("soc cone dimension error");
   for (int i = 0; i < k->qsize; ++i)
     if (k->q[i] < 0) CONE_FAIL("soc cone dimension error");

@@ -1,0 +1,77 @@
+"""B1' drop-in: `_scs_proj_dual_cone` of libscsamd_cones.so against the reference's own
+`_scs_proj_dual_cone` (golden vectors generated from the reference build,
+tests/golden/cones.npz) through the reference's calling convention: lazily normalised box
+bounds via `scal->D`, `r_y` metric, NULL/NULL as the reference's test helpers call it."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from scs_amd import capi
+
+pytestmark = pytest.mark.gpu
+T = capi.T64
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class ScsScaling(C.Structure):  # include/scs_amd.h (reference include/scs_work.h:24-29)
+    _fields_ = [("D", T.fp), ("E", T.fp), ("m", C.c_int), ("n", C.c_int), ("primal_scale", C.c_double),
+                ("dual_scale", C.c_double)]
+
+
+def _lib():
+    l = C.CDLL(capi.lib_path("libscsamd_cones.so"))
+    l._scs_init_cone.restype = C.c_void_p
+    l._scs_init_cone.argtypes = [C.POINTER(T.ScsCone), C.c_int]
+    l._scs_finish_cone.argtypes = [C.c_void_p]
+    l._scs_proj_dual_cone.argtypes = [T.fp, C.c_void_p, C.POINTER(ScsScaling), T.fp]
+    return l
+
+
+def test_proj_dual_cone_matches_reference_golden_vectors():
+    lib = _lib()
+    g = np.load(os.path.join(G, "cones.npz"))
+    meta = json.load(open(os.path.join(G, "cones_meta.json")))
+    assert len(meta) >= 8
+    for name, cone in meta.items():
+        k = capi.make_cone(cone)
+        m = capi.cone_rows(cone)
+        c = lib._scs_init_cone(C.byref(k), m)
+        assert c, name
+        tol = 1e-11 if ("psd" in name or name in ("mixed", "all", "all_c")) else 1e-12
+        for rep in range(2):  # the second round reuses the device workspace (box warm start included)
+            for variant in ("eucl", "ry"):
+                x = np.array(g[f"{name}_{variant}_x"])
+                want = g[f"{name}_{variant}_y"]
+                r = np.array(g[f"{name}_{variant}_r"]) if variant == "ry" else None
+                rc = lib._scs_proj_dual_cone(x.ctypes.data_as(T.fp), c, None,
+                                             r.ctypes.data_as(T.fp) if r is not None else None)
+                assert rc == 0, name
+                err = np.abs(x - want).max() / max(1.0, np.abs(want).max())
+                assert err <= tol, (name, variant, rep, err)
+        lib._scs_finish_cone(c)
+
+
+def test_box_bounds_are_normalised_lazily_from_scal():
+    """src/cones.c:1557-1565 + 1161-1177: with `scal` the box bounds are rescaled by D[j+1]/D[0]
+    at the first projection -- equal to projecting with pre-scaled bounds and no `scal`."""
+    lib = _lib()
+    rng = np.random.default_rng(0)
+    nb = 40
+    bu, bl = rng.uniform(0.5, 2.0, nb), -rng.uniform(0.5, 2.0, nb)
+    D = rng.uniform(0.2, 3.0, nb + 1)
+    x0 = rng.standard_normal(nb + 1) * 3
+    outs = []
+    for cone, scal in ((dict(bu=bu, bl=bl), ScsScaling(D.ctypes.data_as(T.fp), None, nb + 1, 0, 1.0, 1.0)),
+                       (dict(bu=bu * D[1:] / D[0], bl=bl * D[1:] / D[0]), None)):
+        k = capi.make_cone(cone)
+        c = lib._scs_init_cone(C.byref(k), nb + 1)
+        x = x0.copy()
+        assert lib._scs_proj_dual_cone(x.ctypes.data_as(T.fp), c, C.byref(scal) if scal else None, None) == 0
+        outs.append(x)
+        lib._scs_finish_cone(c)
+    assert np.array_equal(np.asarray(k.bu[0:1]), np.asarray(k.bu[0:1]))  # caller's cone untouched (no mutation)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-13, atol=1e-13)
+    assert np.abs(outs[0] - x0).max() > 1e-3

@@ -1,0 +1,45 @@
+"""The reference's OWN test-suite (test/run_tests.c and its problem headers, compiled where
+they lie by oracle/Makefile `conform`) over each drop-in boundary of this repo:
+
+  run_tests_amd_linsys  B1   reference driver + reference cones, OUR linear-system backend
+  run_tests_amd_cones   B1'  reference driver + reference CPU linsys, OUR cone object
+  conform_b2            B2   reference test problems + verification helpers, OUR scs_init/scs_solve
+
+The harnesses are test infrastructure built into oracle/_ref/ (git-ignored, travels to the GPU
+box); without them (no /root/reference at build time) the tests skip."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+
+
+def _run(exe, timeout):
+    path = os.path.join(REF, exe)
+    if not os.path.exists(path):
+        pytest.skip(f"{exe} not built (oracle/Makefile conform needs /root/reference)")
+    p = subprocess.run([path], cwd=REF, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    return p.returncode, p.stdout
+
+
+@pytest.mark.parametrize("exe,count", [("run_tests_amd_linsys", 57), ("run_tests_amd_cones", 57)])
+def test_reference_test_suite_passes_over_our_boundary(exe, count):
+    rc, out = _run(exe, 600)
+    tail = out[-2000:]
+    assert rc == 0, tail
+    assert "ALL TESTS PASSED" in out, tail
+    m = re.search(r"Tests run: (\d+)", out)
+    assert m and int(m.group(1)) == count, tail
+
+
+def test_reference_problems_pass_over_our_whole_solver():
+    rc, out = _run("conform_b2", 600)
+    tail = out[-2000:]
+    assert rc == 0, tail
+    m = re.search(r"CONFORM SUMMARY: (\d+) run, (\d+) failed", out)
+    assert m, tail
+    assert int(m.group(1)) >= 53 and int(m.group(2)) == 0, tail
+    assert "CONFORM FAIL" not in out
