@@ -4,8 +4,9 @@
 Metric (BASELINE.json): "ADMM iters/sec + time-to-eps=1e-4, 1e6-var random SOCP,
 1 GPU".  Workload at N=1: BASELINE configs[1] -- random SOCP n=1e6, m=2e6,
 nnz=1e7 (col_nnz=10), zero + nonnegative + second-order cones, fp64, indirect
-(PCG) linear solves, default SCS settings except acceleration_lookback=0 (Anderson
-acceleration is host-side by design and is reported separately).
+(PCG) linear solves, default SCS settings except acceleration_lookback=0 (on this
+problem family the reference's own safeguard rejects every Anderson step; the AA-on
+figures are in DESIGN.md section 7).
 
 A "step" is ONE ADMM iteration (linear-system solve by PCG + cone projection +
 the vector glue) on inputs resident in HBM.  The run does W untimed warm-up
@@ -46,7 +47,15 @@ def parse():
     ap.add_argument("--no-time-to-eps", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not sample SpMV launches with HIP events in the timed region (roofline left empty)")
+    ap.add_argument("--q-fixed", type=int, default=0,
+                    help="many-small-cones variant of the same workload: every SOC has this size (SURVEY 8d)")
     ap.add_argument("--cpu-sample-n", type=int, default=30000)
+    ap.add_argument("--cpu-omp-sample-n", type=int, default=30000,
+                    help="sample size for the OpenMP flavour of the reference (0 = skip it)")
+    ap.add_argument("--cpu-omp-threads", type=int, default=0, help="default min(nproc, 16)")
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0,
+                    help="hard wall-clock cap (s) for each CPU baseline sample; it runs in a child process")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-i0", type=int, default=20)
     ap.add_argument("--cpu-sample-iters", type=int, default=25)
     ap.add_argument("--max-iters", type=int, default=20000)
@@ -56,19 +65,26 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, full_n):
+def cpu_baseline(args, full_n, threads=1):
     """The reference's own CPU indirect solver (oracle/_ref, built from /root/reference by
     oracle/Makefile) on the host cores, bounded sample: the same generator at a reduced n,
     iterations [i0, i1) isolated by differencing two capped runs (the first iterations solve
-    to 1e-12 and are not representative), scaled linearly in nnz to the full size."""
+    to 1e-12 and are not representative), scaled linearly in nnz to the full size.
+    threads == 1: the stock build; threads > 1: the reference's USE_OPENMP flavour."""
+    flavour = "libscsindir_ref.so" if threads == 1 else "libscsindir_ref_omp.so"
     try:
         from oracle import pyoracle
         from scs_amd import capi, problems
         if not pyoracle.ref_available():
             return None
-        ref = pyoracle.load_ref("libscsindir_ref.so")
-        n = min(args.cpu_sample_n, full_n)
-        pr = problems.random_socp(n, 2 * n, args.col_nnz, seed=args.seed)
+        if threads > 1:
+            os.environ["OMP_NUM_THREADS"] = str(threads)  # read when libgomp initialises (first load)
+            # libgomp's default active spinning makes the reference's many tiny parallel regions
+            # 20x slower than serial whenever anything else shares the cores; passive waiting is its best case
+            os.environ["OMP_WAIT_POLICY"] = "passive"
+        ref = pyoracle.load_ref(flavour)
+        n = min(args.cpu_sample_n if threads == 1 else args.cpu_omp_sample_n, full_n)
+        pr = problems.random_socp(n, 2 * n, args.col_nnz, seed=args.seed, q_fixed=args.q_fixed or None)
         prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
         i0, i1 = args.cpu_sample_i0, args.cpu_sample_i0 + args.cpu_sample_iters
         t0 = time.time()
@@ -78,18 +94,41 @@ def cpu_baseline(args, full_n):
         dt = (rb["solve_time"] - ra["solve_time"]) / 1e3
         its_per_s = (rb["iter"] - ra["iter"]) / dt
         scale = n / float(full_n)
-        return dict(value=its_per_s * scale, unit="ADMM iters/sec", cores=1, kind="reference",
-                    sample=(f"reference libscsindir (linsys/cpu/indirect, 1 thread) on the same generator at "
+        return dict(value=its_per_s * scale, unit="ADMM iters/sec", cores=threads, kind="reference",
+                    sample=(f"reference {flavour} (linsys/cpu/indirect, {threads} thread(s)) on the same generator at "
                             f"n={n}, m={2*n}, nnz={n*args.col_nnz}: ADMM iterations {ra['iter']}..{rb['iter']} in "
                             f"{dt:.2f} s = {its_per_s:.3f} it/s (difference of two capped runs), scaled by "
                             f"n_sample/n_full={scale:g} (cost per iteration is linear in nnz)"),
                     measured_it_per_s=its_per_s, sample_wall_s=wall, host_cores=os.cpu_count())
     except Exception as e:  # the baseline is reported, never required
-        return dict(value=None, unit="ADMM iters/sec", cores=1, kind="reference", sample=f"unavailable: {e}")
+        return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference", sample=f"unavailable: {e}")
+
+
+def cpu_baseline_bounded(args, full_n, threads):
+    """cpu_baseline() in a child process with a hard timeout, so that a slow or oversubscribed
+    host can never stall the bench line (the baseline is reported, never required)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), "--n", str(full_n),
+           "--col-nnz", str(args.col_nnz), "--seed", str(args.seed), "--aa", str(args.aa),
+           "--q-fixed", str(args.q_fixed), "--cpu-sample-n", str(args.cpu_sample_n),
+           "--cpu-omp-sample-n", str(args.cpu_omp_sample_n), "--cpu-sample-i0", str(args.cpu_sample_i0),
+           "--cpu-sample-iters", str(args.cpu_sample_iters)]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                           timeout=args.cpu_baseline_timeout)
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference",
+                    sample=f"unavailable: sample exceeded the {args.cpu_baseline_timeout:.0f} s cap on this host")
+    except Exception as e:
+        return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference", sample=f"unavailable: {e}")
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:  # child of cpu_baseline_bounded: CPU only, no GPU, no torch
+        print(json.dumps(cpu_baseline(args, args.n, threads=args.cpu_baseline_worker)), flush=True)
+        return
     n = args.n
     m = args.m or 2 * n
     rank = int(os.environ.get("RANK", "0"))
@@ -119,7 +158,7 @@ def main():
 
     # ---- synthetic problem, one per rank (seed + rank) --------------------------
     t0 = time.time()
-    pr = problems.random_socp(n, m, col_nnz, seed=seed + rank, dtype=T.np_float)
+    pr = problems.random_socp(n, m, col_nnz, seed=seed + rank, dtype=T.np_float, q_fixed=args.q_fixed or None)
     prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
     t_gen = time.time() - t0
     st = capi.default_settings(lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters, eps_abs=eps,
@@ -222,7 +261,8 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"random SOCP n={n} m={m} nnz={n*col_nnz} (BASELINE configs[1]); "
+            "config": {"workload": f"random SOCP n={n} m={m} nnz={n*col_nnz} (BASELINE configs[1]"
+                                   f"{', many-small-cones variant q_i=%d' % args.q_fixed if args.q_fixed else ''}); "
                                    f"cones z={pr['cone']['z']} l={pr['cone']['l']} soc={len(pr['cone']['q'])}; "
                                    f"indirect PCG; acceleration_lookback={aa}",
                        "n": n, "m": m, "nnz": n * col_nnz, "problems_per_gpu": 1,
@@ -238,7 +278,10 @@ def main():
         }
         out["eps"] = eps
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
-            out["cpu_baseline"] = cpu_baseline(args, n)
+            out["cpu_baseline"] = cpu_baseline_bounded(args, n, 1)
+            if args.cpu_omp_sample_n > 0:  # also the reference's OpenMP flavour on the host cores
+                nthr = args.cpu_omp_threads or min(os.cpu_count() or 1, 16)
+                out["cpu_baseline_omp"] = cpu_baseline_bounded(args, n, max(2, nthr))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
