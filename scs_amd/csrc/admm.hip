@@ -1185,6 +1185,7 @@ static void solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) 
   HIP_CHECK(hipStreamSynchronize(st));
   if (w->accel) aa_host_reset(w->accel);
   if (w->accel_dev) aa_dev_reset(w->accel_dev);
+  w->cone.reset_warm_start(); // every solve starts its PSD eigenbases cold: reruns are bit-identical
   update_work_cache(w);
   if (w->stgs.verbose) print_header(w);
 }

@@ -28,6 +28,9 @@ struct ConeDev {
   int n_psd = 0, psd_kmax = 0;
   DevBuf<int> psd_off, psd_k;
   DevBuf<real> psd_work;    // global scratch for blocks that do not fit in LDS
+  DevBuf<real> psd_vprev;   // per block: eigenbasis of the previous projection (warm start; k <= 72)
+  long long psd_calls = 0;  // projections since the last cold start
+  void reset_warm_start() { psd_calls = 0; }
   // exponential (primal, dual) and power cones: 3 rows each, after the PSD blocks
   int ep = 0, ed = 0, psize = 0, exp_off = 0;
   DevBuf<real> pow_a;       // psize power-cone parameters (negative = dual cone)

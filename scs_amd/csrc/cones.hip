@@ -36,9 +36,11 @@ constexpr double MAX_BOX_VAL = 1e15;  // cones.c:54
 constexpr int PSD_THREADS = 512;
 constexpr int PSD_LDS_KMAX = 92;      // 2*92*93*8 B + 12 KB header = 149 KB < 160 KB
 constexpr int PSD_MAX_SWEEPS = 30;
+constexpr int PSD_WARM_KMAX = 72;     // warm start keeps a third K2 x ld matrix in LDS: 3*72*73*8 B + header < 160 KB
+constexpr int PSD_WARM_RESET = 64;    // cold restart period: bounds the orthogonality drift of the carried basis
 constexpr int PSD_MAX_PAIRS = 512;    // supports k <= 1024
 constexpr int PSD_K_LIMIT = 2 * PSD_MAX_PAIRS;
-constexpr size_t PSD_LDS_HEADER = PSD_MAX_PAIRS * (2 * sizeof(real) + 2 * sizeof(int)) + 8 * sizeof(real);
+constexpr size_t PSD_LDS_HEADER = PSD_MAX_PAIRS * (2 * sizeof(real) + 2 * sizeof(int)) + 10 * sizeof(real);
 
 // ----------------------------------------------------------------------------
 // Moreau pre / post (cones.c:1567-1593)
@@ -230,23 +232,67 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_soc_tile_apply(real *x, const 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #endif
 
+struct alignas(2 * sizeof(real)) RotCS {
+  real c, s;
+};
+
 // packed lower triangle, column major: column j starts at j*k - j*(j-1)/2
 __device__ __forceinline__ int packed_index(int i, int j, int k) { // i >= j
   return j * k - (j * (j - 1)) / 2 + (i - j);
 }
 
+// C(K2 x K2, leading dim ld, in LDS) = op(L) * R with op(L) = L or L', all K2 x K2 in LDS.
+// fp64: v_mfma_f64_16x16x4_f64 tiles (lane l supplies L-operand (row l&15, k l>>4) and R-operand
+// (k l>>4, col l&15); D element (row (l>>4) + 4 reg, col l&15)); fp32 build: plain loops.
+template <bool TRANS_L>
+__device__ __forceinline__ void psd_lds_matmul(real *C, const real *L, const real *R, int K2, int ld, int tid) {
+#ifndef SFLOAT
+  const int wave = tid >> 6, lane = tid & 63, nw = PSD_THREADS >> 6;
+  const int T = (K2 + 15) >> 4, ksteps = (K2 + 3) >> 2;
+  const int li = lane & 15, lk = lane >> 4;
+  for (int t = wave; t < T * T; t += nw) {
+    const int ti = t / T, tj = t % T;
+    f64x4 acc = {0, 0, 0, 0};
+    const int ra = ti * 16 + li, cb = tj * 16 + li;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int kc = ks * 4 + lk;
+      const bool ok = kc < K2;
+      const double av = (ok && ra < K2) ? (TRANS_L ? L[kc * ld + ra] : L[ra * ld + kc]) : 0.0;
+      const double bv = (ok && cb < K2) ? R[kc * ld + cb] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
+      if (i < K2 && j < K2) C[i * ld + j] = acc[r];
+    }
+  }
+#else
+  for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+    const int i = e / K2, j = e % K2;
+    real acc = 0;
+    for (int kc = 0; kc < K2; ++kc) acc += (TRANS_L ? L[kc * ld + i] : L[i * ld + kc]) * R[kc * ld + j];
+    C[i * ld + j] = acc;
+  }
+#endif
+}
+
+// vprev (nullable): per cone a K2m x ldm eigenbasis carried from the previous projection.  With
+// warm != 0 the iteration starts from A' = Vp' A Vp (nearly diagonal when consecutive ADMM
+// iterates are close) and V = Vp, so it needs 1-2 sweeps instead of ~8; the basis is written back
+// whenever vprev is given.  The host restarts cold every PSD_WARM_RESET calls.
 __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *__restrict__ psd_off,
                                                             const int *__restrict__ psd_k, real *scratch,
-                                                            int kmax, int use_lds, int *status) {
+                                                            int kmax, int use_lds, int *status, real *vprev,
+                                                            int warm) {
   // all scratch lives in the dynamic region (16-byte aligned base, guide G17):
-  // [rot_c | rot_s | rot_p | rot_q | red | A | V]
+  // [rot_cs (c,s pairs) | rot_pq (p,q pairs) | red | step flags | A | V]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  real *rot_c = reinterpret_cast<real *>(smem_raw);
-  real *rot_s = rot_c + PSD_MAX_PAIRS;
-  int *rot_p = reinterpret_cast<int *>(rot_s + PSD_MAX_PAIRS);
-  int *rot_q = rot_p + PSD_MAX_PAIRS;
-  real *red = reinterpret_cast<real *>(rot_q + PSD_MAX_PAIRS);
-  real *lds_mat = red + 8;
+  RotCS *rot_cs = reinterpret_cast<RotCS *>(smem_raw);
+  int2 *rot_pq = reinterpret_cast<int2 *>(rot_cs + PSD_MAX_PAIRS);
+  real *red = reinterpret_cast<real *>(rot_pq + PSD_MAX_PAIRS);
+  volatile int *rot_any = reinterpret_cast<volatile int *>(red + 8); // [2]: does step (parity) rotate at all?
+  real *lds_mat = red + 10;
   const int cone = blockIdx.x, tid = threadIdx.x;
   // psd_k > 0: real symmetric block of that order (packed lower triangle).
   // psd_k < 0: complex Hermitian block of order nn = -psd_k/2 (src/cones.c:1072-1155), handled
@@ -299,6 +345,29 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     V[i * ld + j] = i == j ? (real)1 : (real)0;
   }
   __syncthreads();
+  real *Vg = vprev ? vprev + (size_t)cone * K2m * ldm : nullptr;
+  if (Vg && warm) {
+    // V <- Vp;  T <- A Vp;  A <- Vp' T, symmetrised (the rotations assume A == A' exactly)
+    real *Tm = V + (size_t)K2 * ld;
+    for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+      const int i = e / K2, j = e % K2;
+      V[i * ld + j] = Vg[i * ld + j];
+    }
+    __syncthreads();
+    psd_lds_matmul<false>(Tm, A, V, K2, ld, tid);
+    __syncthreads();
+    psd_lds_matmul<true>(A, V, Tm, K2, ld, tid);
+    __syncthreads();
+    for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+      const int i = e / K2, j = e % K2;
+      if (i > j) {
+        const real v = (real)0.5 * (A[i * ld + j] + A[j * ld + i]);
+        A[i * ld + j] = v;
+        A[j * ld + i] = v;
+      }
+    }
+    __syncthreads();
+  }
   real fro = 0;
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
     const real v = A[(e / K2) * ld + (e % K2)];
@@ -308,9 +377,16 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   const real eps = sizeof(real) == 8 ? (real)1e-15 : (real)1e-7;
   int sweep = 0;
   if (fro > (real)0) {
+    // an off-diagonal entry at or below the convergence threshold is left alone; a step
+    // whose pairs are all below it skips the update pass (and its barrier) altogether, so
+    // the last, verifying sweep costs only the pair scan
+    const real thr = eps * fro / (real)k;
+    if (tid < 2) rot_any[tid] = 0;
+    __syncthreads();
     for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
       real offmax = 0;
       for (int step = 0; step < K2 - 1; ++step) {
+        const int par = step & 1;
         // round-robin pairing: player 0 fixed, the others rotate
         if (tid < npairs) {
           const int i = tid;
@@ -325,19 +401,22 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
           const real apq = A[p * ld + q];
           const real aa = absval(apq);
           if (q < k) offmax = aa > offmax ? aa : offmax;
-          if (q < k && aa > (real)0) {
-            const real app = A[p * ld + p], aqq = A[q * ld + q];
-            const real theta = (aqq - app) / ((real)2 * apq);
-            const real t = (theta >= 0 ? (real)1 : (real)-1) / (absval(theta) + sqrt(theta * theta + (real)1));
-            c = (real)1 / sqrt(t * t + (real)1);
+          if (q < k && aa > thr) {
+            // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written
+            // without the first division: t = sgn(d) b / (|d| + sqrt(d^2 + b^2)), d = aqq - app, b = 2 apq
+            const real d = A[q * ld + q] - A[p * ld + p], b = (real)2 * apq;
+            const real h = sqrt(d * d + b * b);
+            const real t = (d >= 0 ? b : -b) / (absval(d) + h);
+            c = rsqrt(t * t + (real)1);
             s = t * c;
+            rot_any[par] = 1;
           }
-          rot_p[i] = p;
-          rot_q[i] = q;
-          rot_c[i] = c;
-          rot_s[i] = s;
+          rot_pq[i] = make_int2(p, q);
+          rot_cs[i] = RotCS{c, s};
+          if (i == 0) rot_any[par ^ 1] = 0; // nobody reads the other parity before the next step's barrier
         }
         __syncthreads();
+        if (!rot_any[par]) continue; // uniform: every pair of this step is already converged
         // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q);
         // V <- V J over (row, pair) items.  One barrier per step for both.
         const int nblk = npairs * npairs, nv = K2 * npairs;
@@ -346,8 +425,10 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
             // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> conflict-free LDS
             // banks); the column pair is uniform across most of a wave
             const int Q = e / npairs, P = e % npairs;
-            const int p1 = rot_p[P], q1 = rot_q[P], p2 = rot_p[Q], q2 = rot_q[Q];
-            const real c1 = rot_c[P], s1 = rot_s[P], c2 = rot_c[Q], s2 = rot_s[Q];
+            const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
+            const RotCS r1 = rot_cs[P], r2 = rot_cs[Q];
+            const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
+            const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
             const real a11 = A[p1 * ld + p2], a12 = A[p1 * ld + q2], a21 = A[q1 * ld + p2], a22 = A[q1 * ld + q2];
             const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
             const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
@@ -357,17 +438,17 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
             A[q1 * ld + q2] = s2 * r21 + c2 * r22;
           } else {
             const int f = e - nblk, Q = f / K2, i = f % K2; // consecutive rows: stride ld
-            const int p2 = rot_p[Q], q2 = rot_q[Q];
-            const real c2 = rot_c[Q], s2 = rot_s[Q];
-            const real vp = V[i * ld + p2], vq = V[i * ld + q2];
-            V[i * ld + p2] = c2 * vp - s2 * vq;
-            V[i * ld + q2] = s2 * vp + c2 * vq;
+            const int2 pq2 = rot_pq[Q];
+            const RotCS r2 = rot_cs[Q];
+            const real vp = V[i * ld + pq2.x], vq = V[i * ld + pq2.y];
+            V[i * ld + pq2.x] = r2.c * vp - r2.s * vq;
+            V[i * ld + pq2.y] = r2.s * vp + r2.c * vq;
           }
         }
         __syncthreads();
       }
       offmax = block_max(offmax, red);
-      if (offmax <= eps * fro / (real)k) break;
+      if (offmax <= thr) break;
     }
   }
   if (sweep >= PSD_MAX_SWEEPS && tid == 0) atomicMax(status, 1); // did not converge (positive: not fatal)
@@ -376,7 +457,9 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
     const int i = e / K2, cidx = e % K2;
     const real lam = A[cidx * ld + cidx];
-    V[i * ld + cidx] *= (cidx < k && lam > (real)0) ? sqrt(lam) : (real)0;
+    const real vv = V[i * ld + cidx];
+    if (Vg) Vg[i * ld + cidx] = vv; // the eigenbasis, for the next projection of this cone
+    V[i * ld + cidx] = vv * ((cidx < k && lam > (real)0) ? sqrt(lam) : (real)0);
   }
   __syncthreads();
   // X+ = W W', lower triangle only, repack with diagonal / sqrt(2)  (cones.c:1052-1063)
@@ -602,6 +685,9 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   up(psd_k, pk);
   if (n_psd && psd_kmax > PSD_LDS_KMAX)
     psd_work.alloc((size_t)n_psd * 2 * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
+  psd_calls = 0;
+  if (n_psd && psd_kmax <= PSD_WARM_KMAX && !getenv("SCS_AMD_PSD_COLD"))
+    psd_vprev.alloc((size_t)n_psd * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
   ep = k->ep;
   ed = k->ed;
   psize = k->psize;
@@ -635,12 +721,15 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
   if (n_psd) {
     const int use_lds = psd_kmax <= PSD_LDS_KMAX;
     const int K2m = (psd_kmax + 1) & ~1;
-    const size_t lds = PSD_LDS_HEADER + (use_lds ? (size_t)2 * K2m * (K2m | 1) * sizeof(real) : 0);
+    const bool carry = psd_vprev.p != nullptr;
+    const size_t lds = PSD_LDS_HEADER + (use_lds ? (size_t)(carry ? 3 : 2) * K2m * (K2m | 1) * sizeof(real) : 0);
+    const int warm = carry && (psd_calls % PSD_WARM_RESET) != 0;
+    ++psd_calls;
     if (lds > 48 * 1024)
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_psd_jacobi),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
-                       psd_work.p, psd_kmax, use_lds, status.p);
+                       psd_work.p, psd_kmax, use_lds, status.p, psd_vprev.p, warm);
   }
   proj_exp_pow(cw);
 }
