@@ -75,3 +75,29 @@ def test_box_bounds_are_normalised_lazily_from_scal():
     assert np.array_equal(np.asarray(k.bu[0:1]), np.asarray(k.bu[0:1]))  # caller's cone untouched (no mutation)
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-13, atol=1e-13)
     assert np.abs(outs[0] - x0).max() > 1e-3
+
+
+def test_psd_warm_start_stays_accurate_over_a_drifting_sequence():
+    """The PSD kernel carries each block's eigenbasis between calls.  Over a
+    slowly drifting sequence -- 150 calls, i.e. across two cold restarts -- every projection must
+    still match an independent numpy eigendecomposition; a jump to an unrelated matrix must too."""
+    from scs_amd import problems
+    lib = capi.load("libscsamd.so")
+    cone = dict(l=3, s=[50, 7, 1, 24])
+    m = capi.cone_rows(cone)
+    k = capi.make_cone(cone)
+    w = lib.scs_amd_cone_init(C.byref(k), m, None)
+    assert w
+    rng = np.random.default_rng(8)
+    base, vel = rng.standard_normal(m), rng.standard_normal(m)
+    worst = 0.0
+    for it in range(150):
+        x = base + 0.01 * it * vel + 1e-3 * rng.standard_normal(m)
+        if it == 100:
+            x = rng.standard_normal(m) * 5  # unrelated input: the carried basis is useless, not harmful
+        want = problems.proj_dual_cone_np(x, cone)
+        got = x.copy()
+        assert lib.scs_amd_cone_proj_dual(w, got.ctypes.data_as(T.fp), None) == 0
+        worst = max(worst, np.abs(got - want).max() / max(1.0, np.abs(want).max()))
+    lib.scs_amd_cone_finish(w)
+    assert worst <= 1e-11, worst
