@@ -27,3 +27,21 @@ for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["tot"]):
     aavg = a["act_tot"] / a["act_n"] if a["act_n"] else 0.0
     print(f"| {short} | {a['n']} | {a['tot']/1e3:.2f} | {100*a['tot']/tot:.1f} | {a['tot']/a['n']:.2f} | {a['mn']:.2f} | "
           f"{a['mx']:.2f} | {a['act_n']} | {aavg:.2f} | {a['vgpr']} | {a['lds']} |")
+
+# ---- gaps between consecutive launches (same stream, in start order): where the time
+# that is not inside kernels goes.  Only gaps < 100 us count (longer ones are host waits).
+ks = c.execute("select start, end, name from kernels order by start").fetchall()
+g_all, g_cg = [], []
+for (s0, e0, n0), (s1, e1, n1) in zip(ks[:-1], ks[1:]):
+    gap = (s1 - e0) / 1000.0
+    if 0 <= gap < 100.0:
+        g_all.append(gap)
+        if ("csr_" in n0 or "k_cg_" in n0) and ("csr_" in n1 or "k_cg_" in n1) and (e0 - s0) > thr * 1000 and (e1 - s1) > thr * 1000:
+            g_cg.append(gap)
+if g_all:
+    import statistics
+    span = (ks[-1][1] - ks[0][0]) / 1e6
+    busy = sum((e - s) for s, e, _ in ks) / 1e6
+    print(f"\n# launch gaps: all {len(g_all)} gaps mean {statistics.mean(g_all):.2f} us median {statistics.median(g_all):.2f} us; "
+          f"between active CG-loop kernels {len(g_cg)} gaps mean {statistics.mean(g_cg) if g_cg else 0:.2f} us "
+          f"median {statistics.median(g_cg) if g_cg else 0:.2f} us; trace span {span:.1f} ms, inside kernels {busy:.1f} ms")

@@ -34,7 +34,7 @@ constexpr int SL_CHUNK = 512;      // products staged per step
 constexpr int SL_MAX_GRID = 16384;
 
 struct SlicedView {
-  int rows, nsb, S;
+  int rows, nsb, S, bits; // bits: log2(columns per slice)
   const int *sbrow;       // nsb + 1 : first row of each super-block
   const int *segoff;      // nsb * (S + 1) : start of each (super-block, slice) run
   const unsigned *sidx;   // nnz : (col & 0xffff) | local_row << 16
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_sliced_kernel(SlicedView A, 
   real *red = reinterpret_cast<real *>(sr + SL_CHUNK); // 8-byte aligned: SL_CHUNK * 2 B is a multiple of 8
   constexpr int U = SL_CHUNK / SCSAMD_BLOCK;
   const int tid = threadIdx.x;
-  const unsigned mask = (1u << SL_SLICE_BITS) - 1;
+  const int bits = A.bits;
+  const unsigned mask = (1u << bits) - 1;
   real dot = 0;
   for (int b = blockIdx.x; b < A.nsb; b += gridDim.x) {
     const int r0 = A.sbrow[b], nr = A.sbrow[b + 1] - r0;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_sliced_kernel(SlicedView A, 
     const int *so = A.segoff + (size_t)b * (A.S + 1);
     for (int s = 0; s < A.S; ++s) {
       const int e0 = so[s], e1 = so[s + 1];
-      const real *xs = x + ((size_t)s << SL_SLICE_BITS);
+      const real *xs = x + ((size_t)s << bits);
       for (int base = e0; base < e1; base += SL_CHUNK) {
         const int cnt = min(SL_CHUNK, e1 - base);
         unsigned w[U];
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_sliced_kernel(SlicedView A, 
           const int k = tid + j * SCSAMD_BLOCK;
           if (k < cnt) {
             sp[k] = v[j] * xx[j];
-            sr[k] = (unsigned short)(w[j] >> SL_SLICE_BITS);
+            sr[k] = (unsigned short)(w[j] >> bits);
           }
         }
         __syncthreads();
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_sliced_kernel(SlicedView A, 
 
 struct SlicedDev {
   bool built = false;
-  int rows = 0, cols = 0, nsb = 0, S = 0, accrows = 0;
+  int rows = 0, cols = 0, nsb = 0, S = 0, accrows = 0, bits = SL_SLICE_BITS;
   DevBuf<int> sbrow, segoff;
   DevBuf<unsigned> sidx;
   DevBuf<real> sval;
-  SlicedView view() const { return SlicedView{rows, nsb, S, sbrow.p, segoff.p, sidx.p, sval.p}; }
+  SlicedView view() const { return SlicedView{rows, nsb, S, bits, sbrow.p, segoff.p, sidx.p, sval.p}; }
   int grid() const { return std::max(1, std::min(nsb, SL_MAX_GRID)); }
   size_t lds_bytes() const {
     return (size_t)accrows * sizeof(real) + SL_CHUNK * (sizeof(real) + sizeof(unsigned short)) + 8 * sizeof(real);
@@ -140,7 +141,9 @@ struct SlicedDev {
   void build(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval, hipStream_t st) {
     rows = rows_;
     cols = cols_;
-    S = std::max(1, (cols + (1 << SL_SLICE_BITS) - 1) >> SL_SLICE_BITS);
+    bits = SL_SLICE_BITS;
+    if (const char *e = getenv("SCS_AMD_SLICE_BITS")) bits = std::max(10, std::min(19, atoi(e)));
+    S = std::max(1, (cols + (1 << bits) - 1) >> bits);
     std::vector<int> sb;
     sb.push_back(0);
     int r = 0;
@@ -168,15 +171,15 @@ struct SlicedDev {
     for (int b = 0; b < nsb; ++b) {
       const int k0 = hptr[sb[b]], k1 = hptr[sb[b + 1]];
       std::fill(cnt.begin(), cnt.end(), 0);
-      for (int k = k0; k < k1; ++k) cnt[(hidx[k] >> SL_SLICE_BITS) + 1]++;
+      for (int k = k0; k < k1; ++k) cnt[(hidx[k] >> bits) + 1]++;
       for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
       for (int s = 0; s <= S; ++s) so[(size_t)b * (S + 1) + s] = k0 + cnt[s];
       for (int s = 0; s < S; ++s) nx[s] = cnt[s];
       for (int rr = sb[b]; rr < sb[b + 1]; ++rr)
         for (int k = hptr[rr]; k < hptr[rr + 1]; ++k) {
-          const int s = hidx[k] >> SL_SLICE_BITS;
+          const int s = hidx[k] >> bits;
           const size_t q = (size_t)k0 + nx[s]++;
-          hi[q] = (unsigned)(hidx[k] & ((1 << SL_SLICE_BITS) - 1)) | ((unsigned)(rr - sb[b]) << SL_SLICE_BITS);
+          hi[q] = (unsigned)(hidx[k] & ((1 << bits) - 1)) | ((unsigned)(rr - sb[b]) << bits);
           hv[q] = hval[k];
         }
     }
