@@ -236,6 +236,8 @@ def main():
             avg_s = spmv_ms / spmv_samples * 1e-3
             roof["achieved"] = bytes_per_spmv / avg_s / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+            # context only: the best pure streaming kernel measured on this chip (lab/spmv_lab.hip) reaches 6.9 TB/s
+            roof["frac_of_measured_stream_6900GBs"] = roof["achieved"] / 6900.0
             roof["avg_launch_us"] = avg_s * 1e6
             roof["algorithmic_bytes_per_launch"] = bytes_per_spmv
             roof["launches_timed"] = int(spmv_samples)
