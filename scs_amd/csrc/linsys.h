@@ -21,7 +21,7 @@ struct CgCtl {
   int zero_rhs;  // ||b||_inf <= 1e-12: solution is 0, everything else is skipped
   int cg_done;   // converged (or breakdown): remaining iteration kernels return
   int iters;     // PCG iterations performed (reference counting, private.c:203,216)
-  int pad;
+  int max_its;   // 10 n (private.c:307): the device stops there even if more iterations were enqueued
 };
 
 struct LinSys {
@@ -46,8 +46,15 @@ struct LinSys {
   // staging for the host-pointer boundary (B1)
   DevBuf<real> b_stage, s_stage, dr_stage;
 
+  // HIP graph of CG_GRAPH_ITERS iterations (4 kernels each, constant arguments: everything that
+  // changes lives in the control block) for systems whose kernels are shorter than a launch
+  hipGraphExec_t cg_graph = nullptr;
+  real *cg_x = nullptr; // solution vector of the current / captured solve
+  bool cg_graph_tried = false, use_graph = false;
+  void enqueue_cg_iteration(int q);
+  bool build_cg_graph();
   // statistics / profiling
-  long long tot_cg_its = 0, n_solves = 0, n_matvecs = 0, n_spmv = 0;
+  long long tot_cg_its = 0, n_solves = 0, n_matvecs = 0, n_spmv = 0, n_graph_launches = 0;
   int last_its = 16;
   bool profiling = false;
   EventTimer spmv_timer, cg_timer;

@@ -20,6 +20,10 @@
 
 namespace scsamd {
 
+constexpr int CG_GRAPH_ITERS = 8;               // iterations per captured graph (even: slot parity q = iteration & 1)
+constexpr long long CG_GRAPH_MAX_NNZ = 2000000; // systems up to this many nonzeros replay the CG loop from a graph
+
+
 constexpr int VEC_MAX_GRID = 2048;
 constexpr int PART_CAP = SL_MAX_GRID; // >= SPMV_MAX_GRID, >= SL_MAX_GRID and >= 2 * VEC_MAX_GRID
 
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_rhs_prep(real *b, const real *
                                                            real *tmp, int n, int m,
                                                            const real *part, int pcount, CgCtl *ctl,
                                                            real tol, const real *warm_part,
-                                                           int warm_cnt, real warm_scale) {
+                                                           int warm_cnt, real warm_scale, int max_its) {
   __shared__ real red[4];
   const real nb = reduce_partials_max(part, pcount, red);
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_rhs_prep(real *b, const real *
     ctl->zero_rhs = zero ? 1 : 0;
     ctl->cg_done = zero ? 1 : 0;
     ctl->iters = 0;
+    ctl->max_its = max_its;
     ctl->tol = t;
     ctl->rhs_norm = nb;
     ctl->norm_r = 0;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const re
     ctl->ztr[parity ^ 1] = ztr;
     ctl->norm_r = nr;
     if (!brk) ctl->iters += 1; // converged at i -> i+1 ; breakdown returns i (private.c:203,216)
-    if (conv || brk) ctl->cg_done = 1;
+    if (conv || brk || ctl->iters >= ctl->max_its) ctl->cg_done = 1;
   }
 }
 
@@ -384,6 +389,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_linsys_fused(CsrView A, CsrVi
 // host side
 // ----------------------------------------------------------------------------
 LinSys::~LinSys() {
+  if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
   if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -535,6 +541,10 @@ void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s,
     // this is for genuinely tiny systems only, where a CG iteration is pure launch latency
     use_fused = nnzA <= 4096 && n <= 1024 && m <= 4096;
     if (const char *e = getenv("SCS_AMD_FUSED")) use_fused = atoi(e) != 0;
+    // below this size a CG kernel is shorter than the host's cost of launching it: replay the
+    // iterations from a captured graph instead (above it launches are hidden behind the kernels)
+    use_graph = nnzA <= CG_GRAPH_MAX_NNZ;
+    if (const char *e = getenv("SCS_AMD_GRAPH")) use_graph = atoi(e) != 0;
   }
   rx.alloc(n);
   ry.alloc(m);
@@ -603,11 +613,65 @@ void LinSys::harvest_timers() {
   cg_timer.harvest();
 }
 
+
+// one PCG iteration = K1 (z = R_y^-1 A p), [P p], K2 (Gp, partial p'Gp), K3 (alpha, x, r, z, partial
+// z'r, |r|), K4 (stop test, beta, p); `b` is where the solve keeps x: always b_stage / the caller's
+// device vector, fixed per LinSys user, so it is passed through cg_x
+void LinSys::enqueue_cg_iteration(int q) {
+  CgCtl *c = ctl.p;
+  const int gv = vec_grid(n);
+  const int gAt = (At.sliced && At.sliced->built) ? At.sliced->grid() : At.grid();
+  real *part_pgp = partA.p, *part_ztr = partB.p, *part_max = partB.p + PART_CAP / 2;
+  EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
+  launch_spmv(EPI_DIV, A, p.p, tmp.p, e1, &c->cg_done);
+  if (has_P) {
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr};
+    launch_spmv(EPI_PLAIN, P, p.p, Pp.p, ep, &c->cg_done);
+  }
+  EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, part_pgp};
+  launch_spmv(EPI_GP, At, tmp.p, Gp.p, e2, &c->cg_done);
+  hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, cg_x, r.p, z.p, p.p, Gp.p, M.p, n,
+                     part_pgp, gAt, part_ztr, part_max, c, q);
+  hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, part_ztr, part_max,
+                     gv, c, q);
+}
+
+// Capture CG_GRAPH_ITERS iterations into an executable graph.  Any failure leaves cg_graph null
+// and the loop keeps launching kernels one by one (same kernels, same order).
+bool LinSys::build_cg_graph() {
+  cg_graph_tried = true;
+  hipGraph_t g = nullptr;
+  if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  bool ok = true;
+  try {
+    for (int j = 0; j < CG_GRAPH_ITERS; ++j) enqueue_cg_iteration(j & 1);
+  } catch (...) {
+    ok = false;
+  }
+  if (hipStreamEndCapture(stream, &g) != hipSuccess || !g) ok = false;
+  if (ok && hipGraphInstantiate(&cg_graph, g, nullptr, nullptr, 0) != hipSuccess) {
+    cg_graph = nullptr;
+    ok = false;
+  }
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  return ok;
+}
+
 int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, int warm_cnt,
                       real warm_scale) {
   const int gv = vec_grid(n), gnm = vec_grid((long long)n + m);
   CgCtl *c = ctl.p;
   static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
+  if (cg_x != b) { // the captured graph bakes the solution vector's address in
+    if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
+    cg_graph = nullptr;
+    cg_graph_tried = false;
+    cg_x = b;
+  }
   int cg_slot = -1;
   if (profiling) cg_slot = cg_timer.start(stream);
 
@@ -633,7 +697,8 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
 
   hipLaunchKernelGGL(k_absmax_partial, dim3(gnm), dim3(SCSAMD_BLOCK), 0, stream, b, n + m, partA.p);
   hipLaunchKernelGGL(k_rhs_prep, dim3(gnm), dim3(SCSAMD_BLOCK), 0, stream, b, ry.p, tmp.p, n, m, partA.p,
-                     gnm, c, tol, warm_part, warm_cnt, warm_scale);
+                     gnm, c, tol, warm_part, warm_cnt, warm_scale,
+                     (int)std::min<long long>(10LL * n, 2147483647LL));
   // b_x += A' R_y^-1 r_y   (private.c:305)
   {
     EpiArgs e{nullptr, nullptr, nullptr, nullptr};
@@ -658,25 +723,19 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
   const long long max_its = 10LL * n; // private.c:307
   long long it = 0;
   int batch = std::max(4, std::min(last_its + 1, 4096));
-  const int gAt = (At.sliced && At.sliced->built) ? At.sliced->grid() : At.grid();
   // partial arrays: partA <- p'Gp (K2), partB <- z'r and partB+PART_CAP/2 <- |r| (K3)
-  real *part_pgp = partA.p, *part_ztr = partB.p, *part_max = partB.p + PART_CAP / 2;
+  if (use_graph && !profiling && !cg_graph_tried) build_cg_graph();
   for (;;) {
-    const int nb = (int)std::min<long long>(batch, max_its - it);
-    for (int j = 0; j < nb; ++j) {
-      const int q = (int)((it + j) & 1);
-      EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
-      launch_spmv(EPI_DIV, A, p.p, tmp.p, e1, &c->cg_done);
-      if (has_P) {
-        EpiArgs ep{nullptr, nullptr, nullptr, nullptr};
-        launch_spmv(EPI_PLAIN, P, p.p, Pp.p, ep, &c->cg_done);
-      }
-      EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, part_pgp};
-      launch_spmv(EPI_GP, At, tmp.p, Gp.p, e2, &c->cg_done);
-      hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, b, r.p, z.p, p.p, Gp.p, M.p,
-                         n, part_pgp, gAt, part_ztr, part_max, c, q);
-      hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, part_ztr,
-                         part_max, gv, c, q);
+    int nb = (int)std::min<long long>(batch, max_its - it);
+    if (cg_graph && !profiling) {
+      // whole graphs only (the parity of the double-buffered z'r slot restarts with each graph);
+      // iterations enqueued past convergence are no-ops, as with individual launches
+      const int ng = (nb + CG_GRAPH_ITERS - 1) / CG_GRAPH_ITERS;
+      for (int g = 0; g < ng; ++g) HIP_CHECK(hipGraphLaunch(cg_graph, stream));
+      n_graph_launches += ng;
+      nb = ng * CG_GRAPH_ITERS;
+    } else {
+      for (int j = 0; j < nb; ++j) enqueue_cg_iteration((int)((it + j) & 1));
     }
     it += nb;
     HIP_CHECK(hipMemcpyAsync(hctl.p, c, sizeof(CgCtl), hipMemcpyDeviceToHost, stream));
