@@ -94,3 +94,60 @@ def test_random_mixed_cone_program_matches_reference(seed):
     assert np.abs(_ref_proj_dual(ref, cone, ya) - ya).max() <= 1e-6 * max(1.0, np.abs(ya).max())   # y in K*
     assert np.abs(_ref_proj_dual(ref, cone, -sa)).max() <= 1e-6 * max(1.0, np.abs(sa).max())       # s in K
     assert abs(float(ya @ sa)) <= 1e-4 * max(1.0, np.abs(ya).max() * np.abs(sa).max())
+
+
+def _base_problem(seed):
+    rng = np.random.default_rng(5000 + seed)
+    cone = dict(z=2, l=int(rng.integers(4, 10)), q=[int(v) for v in rng.integers(2, 8, size=2)], s=[3])
+    m = capi.cone_rows(cone)
+    n = max(3, m // 3)
+    A = sp.random(m, n, density=min(1.0, 5.0 / n), random_state=seed, format="lil", data_rvs=rng.standard_normal)
+    return rng, cone, m, n, A
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_infeasible_programs_get_the_reference_status_and_a_certificate(seed):
+    """Two contradictory rows in the nonnegative cone (x0 <= -1 and x0 >= 1): primal infeasible.
+    Same status as the reference (SCS_INFEASIBLE = -2) and a valid certificate: A'y ~ 0, b'y < 0, y in K*."""
+    ref = pyoracle.load_ref()
+    amd = capi.load("libscsamd.so")
+    rng, cone, m, n, A = _base_problem(seed)
+    b = rng.standard_normal(m)
+    l0 = cone["z"]                       # first two rows of the l-block
+    A[l0, :] = 0; A[l0, 0] = 1.0; b[l0] = -1.0       #  x0 + s = -1, s >= 0  ->  x0 <= -1
+    A[l0 + 1, :] = 0; A[l0 + 1, 0] = -1.0; b[l0 + 1] = -1.0   # -x0 + s = -1       ->  x0 >= 1
+    A = sp.csc_matrix(A)
+    c = rng.standard_normal(n)
+    prob = capi.Problem(A, b, c, cone)
+    ra = capi.solve(amd, prob, verbose=0)
+    rr = capi.solve(ref, prob, verbose=0)
+    assert ra["info"]["status_val"] == rr["info"]["status_val"] == -2, (ra["info"]["status"], rr["info"]["status"])
+    y = ra["y"]
+    assert float(b @ y) < 0
+    y = y / -float(b @ y)                # normalised like the reference: b'y = -1
+    assert np.abs(A.T @ y).max() <= 1e-5
+    assert np.abs(_ref_proj_dual(ref, cone, y) - y).max() <= 1e-6 * max(1.0, np.abs(y).max())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_unbounded_programs_get_the_reference_status_and_a_certificate(seed):
+    """A variable that no row touches, with negative cost: unbounded below.  Same status as the
+    reference (SCS_UNBOUNDED = -1) and a valid certificate: Ax + s ~ 0, s in K, c'x < 0."""
+    ref = pyoracle.load_ref()
+    amd = capi.load("libscsamd.so")
+    rng, cone, m, n, A = _base_problem(seed + 50)
+    A[:, n - 1] = 0                      # last variable is free of every constraint ...
+    A = sp.csc_matrix(A)
+    c = np.abs(rng.standard_normal(n))
+    c[n - 1] = -1.0                      # ... and pays for going to +infinity
+    b = np.abs(rng.standard_normal(m)) + 0.5
+    prob = capi.Problem(A, b, c, cone)
+    ra = capi.solve(amd, prob, verbose=0)
+    rr = capi.solve(ref, prob, verbose=0)
+    assert ra["info"]["status_val"] == rr["info"]["status_val"] == -1, (ra["info"]["status"], rr["info"]["status"])
+    x, s = ra["x"], ra["s"]
+    cx = float(c @ x)
+    assert cx < 0
+    x, s = x / -cx, s / -cx              # c'x = -1
+    assert np.abs(A @ x + s).max() <= 1e-5
+    assert np.abs(_ref_proj_dual(ref, cone, -s)).max() <= 1e-6 * max(1.0, np.abs(s).max())   # s in K
