@@ -24,7 +24,7 @@ constexpr int CG_GRAPH_ITERS = 8;               // iterations per captured graph
 constexpr long long CG_GRAPH_MAX_NNZ = 2000000; // systems up to this many nonzeros replay the CG loop from a graph
 
 
-constexpr int VEC_MAX_GRID = 2048;
+constexpr int VEC_MAX_GRID = 512; // every consumer workgroup re-reduces the producers' partials: 2048 WGs cost K4 64 MB of L2 reads (measured 2.5 % of a CG iteration)
 constexpr int PART_CAP = SL_MAX_GRID; // >= SPMV_MAX_GRID, >= SL_MAX_GRID and >= 2 * VEC_MAX_GRID
 
 CsrDev::~CsrDev() { delete sliced; }

@@ -147,7 +147,8 @@ struct SlicedDev {
     std::vector<int> sb;
     sb.push_back(0);
     int r = 0;
-    const long long nnz_sb = std::max<long long>(SL_NNZ_SB, ((long long)hptr[rows] + SL_TARGET_WGS - 1) / SL_TARGET_WGS);
+    long long nnz_sb = std::max<long long>(SL_NNZ_SB, ((long long)hptr[rows] + SL_TARGET_WGS - 1) / SL_TARGET_WGS);
+    if (const char *e = getenv("SCS_AMD_SL_NNZ_SB")) nnz_sb = std::max(1024, atoi(e)); // experiments
     while (r < rows) {
       const int s0 = r;
       long long acc = 0;
