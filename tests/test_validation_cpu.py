@@ -89,3 +89,18 @@ def test_solve_with_null_arguments_fails_cleanly(lib):
     T = lib._scs_types
     info = T.ScsInfo()
     assert lib.scs_solve(None, None, C.byref(info), 0) == -4   # SCS_FAILED
+
+
+def test_python_solver_object_reports_missing_gpu_or_bad_data():
+    """scs_amd.solver.SCS (the scs-python-shaped object): malformed data is rejected before any
+    device work; without a GPU the constructor fails loudly (no CPU fallback)."""
+    import numpy as np
+    import scipy.sparse as sp
+    from scs_amd.solver import SCS
+    A = sp.csc_matrix(np.eye(3))
+    with pytest.raises(ValueError):
+        SCS(dict(A=A, b=np.ones(3)), dict(l=3))
+    lib_ = capi.load("libscsamd.so")
+    if lib_.scs_amd_device_count() <= 0:
+        with pytest.raises(ValueError, match="ScsWork allocation error"):
+            SCS(dict(A=A, b=np.ones(3), c=np.ones(3)), dict(l=3))
