@@ -41,6 +41,19 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 }
 #define HIP_CHECK(x) ::scsamd::hip_check((x), #x, __FILE__, __LINE__)
 
+// one zero-fill stream per host thread (re-created if the thread switches device), never destroyed
+inline hipStream_t fill_stream() {
+  static thread_local hipStream_t st = nullptr;
+  static thread_local int st_dev = -1;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  if (!st || st_dev != dev) {
+    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    st_dev = dev;
+  }
+  return st;
+}
+
 // ---- device buffer (RAII) -------------------------------------------------
 template <typename T> struct DevBuf {
   T *p = nullptr;
@@ -56,11 +69,14 @@ template <typename T> struct DevBuf {
     // always allocate a little slack so 16-byte vector loads that start inside
     // the array may run a few elements past its logical end
     HIP_CHECK(hipMalloc((void **)&p, (count + 8) * sizeof(T)));
-    HIP_CHECK(hipMemset(p, 0, (count + 8) * sizeof(T)));
-    // hipMemset runs on the legacy default stream and may return before the fill
-    // has happened; our work streams are non-blocking (no implicit ordering with
-    // it), so drain it here.  Allocation only happens at init time.
-    HIP_CHECK(hipStreamSynchronize(nullptr));
+    // Zero-fill on a private non-blocking stream and wait for it: the fill must have happened
+    // before any work stream touches the buffer (they have no implicit ordering with it), and it
+    // must NOT go through the legacy default stream -- any legacy-stream operation fails with
+    // hipErrorStreamCaptureImplicit while another host thread is capturing a HIP graph (the PCG
+    // loop of a concurrent solve does exactly that).
+    hipStream_t fs = fill_stream();
+    HIP_CHECK(hipMemsetAsync(p, 0, (count + 8) * sizeof(T), fs));
+    HIP_CHECK(hipStreamSynchronize(fs));
   }
   void release() {
     if (p) (void)hipFree(p);

@@ -641,7 +641,9 @@ void LinSys::enqueue_cg_iteration(int q) {
 bool LinSys::build_cg_graph() {
   cg_graph_tried = true;
   hipGraph_t g = nullptr;
-  if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+  // relaxed: other host threads (concurrent solves, each on its own stream) keep allocating and
+  // copying while this thread captures; nothing they do touches this stream
+  if (hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }

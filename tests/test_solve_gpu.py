@@ -235,3 +235,26 @@ def test_sigint_during_solve_returns_scs_sigint():
     # and the library is usable afterwards
     r2 = capi.solve(amd, prob, verbose=0, max_iters=50)
     assert r2["info"]["status_val"] in (1, 2)
+
+
+def test_concurrent_solves_from_several_host_threads_with_cg_graphs():
+    """Workspaces are independent (reference include/scs.h:271-324: one caller thread per workspace,
+    any number of workspaces).  Several host threads run scs_init / scs_solve at the same time; the
+    PCG loops replay captured HIP graphs (these systems are below the graph threshold), so one
+    thread allocates and uploads while another is inside a stream capture.  Every result must equal
+    the single-threaded one bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    amd = capi.load("libscsamd.so")
+    probs = []
+    for sd in range(6):
+        pr = problems.random_socp(2000 + 300 * sd, 6000 + 900 * sd, 8, seed=40 + sd)
+        probs.append(capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"]))
+    kw = dict(verbose=0, acceleration_lookback=0, max_iters=300)
+    serial = [capi.solve(amd, p, **kw) for p in probs]
+    for _ in range(2):
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            par = list(ex.map(lambda p: capi.solve(amd, p, **kw), probs))
+        for a, b in zip(serial, par):
+            assert a["info"]["status_val"] == b["info"]["status_val"]
+            assert a["info"]["iter"] == b["info"]["iter"]
+            assert np.array_equal(a["x"], b["x"])
