@@ -97,3 +97,22 @@ def test_two_rank_gloo_batch_matches_serial():
         info = pyoracle.oracle_solve(prob, max_iters=400)["info"]
         assert int(tab[j, 0]) == j and int(tab[j, 2]) == info["iter"]
         assert abs(tab[j, 3] - info["pobj"]) <= 1e-12 * max(1, abs(info["pobj"]))
+
+
+def test_bench_cpu_baseline_worker_runs_without_a_gpu():
+    """bench.py's cpu_baseline leg is a CPU-only child process (the reference build on the host
+    cores); it must work where there is no GPU and print one JSON object."""
+    import json
+    import subprocess
+    import sys
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-worker", "1", "--n", "100000",
+                          "--cpu-sample-n", "1500", "--cpu-sample-i0", "5", "--cpu-sample-iters", "10"],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["kind"] == "reference" and d["cores"] == 1 and d["unit"] == "ADMM iters/sec"
+    assert d["value"] is not None and d["value"] > 0, d
+    assert "n=1500" in d["sample"]
