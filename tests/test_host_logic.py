@@ -5,6 +5,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from scs_amd import batch, capi, problems
 
