@@ -105,6 +105,7 @@ def restatement():
     lib.or_linsys_free.argtypes = [C.c_void_p]
     lib.or_cone_init.restype = C.c_void_p
     lib.or_cone_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _ip, C.c_int, _ip, _dp]
+    lib.or_cone_set_extra.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, C.c_int, C.c_int, _dp]
     lib.or_cone_proj_dual.argtypes = [C.c_void_p, _dp, _dp]
     lib.or_cone_free.argtypes = [C.c_void_p]
     lib.or_accum_by_atrans.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp]
@@ -131,6 +132,11 @@ def oracle_proj_dual_cone(cone, x, r_y=None, D=None):
     m = len(x)
     Dd = None if D is None else _np.ascontiguousarray(D, dtype=_np.float64)
     c = lib.or_cone_init(m, z, l, bsize, _d(bl), _d(bu), len(q), _i(q), len(s), _i(s), _d(Dd))
+    cs = _np.ascontiguousarray(cone.get("cs", []), dtype=_np.int32)
+    pw = _np.ascontiguousarray(cone.get("p", []), dtype=_np.float64)
+    ep, ed = int(cone.get("ep", 0)), int(cone.get("ed", 0))
+    if len(cs) or ep or ed or len(pw):
+        lib.or_cone_set_extra(c, len(cs), _i(cs), ep, ed, len(pw), _d(pw))
     out = _np.array(x, dtype=_np.float64)
     r = None if r_y is None else _np.ascontiguousarray(r_y, dtype=_np.float64)
     lib.or_cone_proj_dual(c, _d(out), _d(r))

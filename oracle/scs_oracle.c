@@ -14,12 +14,13 @@
  *      that build is present.
  *
  * Scope: double precision, int32 indices, P == NULL (no BASELINE config has a
- * quadratic term), cones zero / nonneg / box / second-order / PSD, Anderson
- * acceleration off (the reference object src/aa.c stays host side and is not
- * restated here).  PSD uses a cyclic Jacobi eigensolver instead of LAPACK dsyevr.
- * Exponential and power cones (added to the HIP path after the hot path) are
- * NOT restated: the HIP kernels for them are checked directly against golden vectors
- * captured from the reference and against the reference's own exp/power test problems.
+ * quadratic term), Anderson acceleration off (src/aa.c is restated separately, in the
+ * product's host AA, and pinned against the reference object in tests/test_aa_host.py).
+ * Cone PROJECTIONS: every cone the HIP path carries -- zero / nonneg / box / second-order /
+ * PSD / complex PSD / exponential (primal, dual) / power (primal, dual); PSD and complex
+ * PSD use a cyclic Jacobi eigensolver instead of LAPACK dsyevr / zheevr.  The whole-solve
+ * restatement (or_solve) takes the zero / nonneg / box / SOC / PSD cones of the BASELINE
+ * configs; the other cones' whole solves are checked against the real reference only.
  */
 #include "scs_oracle.h"
 
@@ -277,23 +278,12 @@ static double cone_box(double *tx, const double *bl, const double *bu, int bsize
   return t;
 }
 
-/* cones.c:999-1067 with the LAPACK dsyevr/dsyrk pair replaced by cyclic Jacobi */
-static void cone_psd(double *X, int k) {
-  double *A, *V, sqrt2 = sqrt(2.0), fro = 0;
+/* PSD part of a full symmetric k x k matrix (row major, overwritten): cyclic Jacobi in place of the
+ * LAPACK dsyevr/dsyrk pair of cones.c:1028-1052 */
+static void psd_part_full(double *A, int k) {
+  double *V, fro = 0;
   int i, j, c, sweep, p, q;
-  if (k == 0) return;
-  if (k == 1) {
-    X[0] = MAXV(X[0], 0.);
-    return;
-  }
-  A = (double *)calloc((size_t)k * k, sizeof(double));
   V = (double *)calloc((size_t)k * k, sizeof(double));
-  for (j = 0; j < k; ++j)
-    for (i = j; i < k; ++i) { /* packed lower triangle, column major (cones.c:1018-1021) */
-      double v = X[j * k - (j * (j - 1)) / 2 + (i - j)];
-      if (i == j) v *= sqrt2;
-      A[i * k + j] = A[j * k + i] = v;
-    }
   for (i = 0; i < k; ++i) V[i * k + i] = 1.0;
   for (i = 0; i < k * k; ++i) fro += A[i] * A[i];
   fro = sqrt(fro);
@@ -323,23 +313,305 @@ static void cone_psd(double *X, int k) {
       }
     if (off <= 1e-16 * fro) break;
   }
-  /* X+ = sum_{lambda > 0} lambda v v'  (cones.c:1036-1052); diagonal / sqrt(2) (:1055) */
-  for (j = 0; j < k; ++j)
-    for (i = j; i < k; ++i) {
-      double acc = 0;
-      for (c = 0; c < k; ++c) {
-        double lam = A[c * k + c];
-        if (lam > 0) acc += lam * V[i * k + c] * V[j * k + c];
+  { /* A <- sum_{lambda > 0} lambda v v' */
+    double *lam = (double *)calloc((size_t)k, sizeof(double));
+    for (c = 0; c < k; ++c) lam[c] = A[c * k + c];
+    for (i = 0; i < k; ++i)
+      for (j = 0; j < k; ++j) {
+        double acc = 0;
+        for (c = 0; c < k; ++c)
+          if (lam[c] > 0) acc += lam[c] * V[i * k + c] * V[j * k + c];
+        A[i * k + j] = acc;
       }
-      if (i == j) acc /= sqrt2;
-      X[j * k - (j * (j - 1)) / 2 + (i - j)] = acc;
+    free(lam);
+  }
+  free(V);
+}
+
+/* cones.c:999-1067: packed lower triangle (column major, off-diagonals pre-scaled by sqrt 2) */
+static void cone_psd(double *X, int k) {
+  double *A, sqrt2 = sqrt(2.0);
+  int i, j;
+  if (k == 0) return;
+  if (k == 1) {
+    X[0] = MAXV(X[0], 0.);
+    return;
+  }
+  A = (double *)calloc((size_t)k * k, sizeof(double));
+  for (j = 0; j < k; ++j)
+    for (i = j; i < k; ++i) { /* cones.c:1018-1025 */
+      double v = X[j * k - (j * (j - 1)) / 2 + (i - j)];
+      if (i == j) v *= sqrt2;
+      A[i * k + j] = A[j * k + i] = v;
+    }
+  psd_part_full(A, k);
+  for (j = 0; j < k; ++j)
+    for (i = j; i < k; ++i) { /* diagonal / sqrt(2), cones.c:1055 */
+      double v = A[i * k + j];
+      if (i == j) v /= sqrt2;
+      X[j * k - (j * (j - 1)) / 2 + (i - j)] = v;
     }
   free(A);
-  free(V);
+}
+
+/* complex Hermitian PSD cone, cones.c:1072-1155 (LAPACK zheevr there).  Packed layout: column c
+ * of the lower triangle starts at c (2 nn - c): the real diagonal entry, then (re, im) pairs of
+ * rows c+1..nn-1, off-diagonals pre-scaled by sqrt 2.  Solved through the real symmetric embedding
+ * M = [[A, -B], [B, A]] of H = A + iB: the PSD part of M is the embedding of the PSD part of H. */
+static void cone_cpsd(double *X, int nn) {
+  const int K = 2 * nn;
+  double *M, sqrt2 = sqrt(2.0);
+  int r, c;
+  if (nn == 0) return;
+  if (nn == 1) {
+    X[0] = MAXV(X[0], 0.);
+    return;
+  }
+  M = (double *)calloc((size_t)K * K, sizeof(double));
+  for (c = 0; c < nn; ++c) {
+    const double *col = X + c * (2 * nn - c);
+    const double d = col[0] * sqrt2;
+    M[c * K + c] = d;
+    M[(c + nn) * K + (c + nn)] = d;
+    for (r = c + 1; r < nn; ++r) {
+      const double re = col[1 + 2 * (r - c - 1)], im = col[2 + 2 * (r - c - 1)]; /* H[r][c] */
+      M[r * K + c] = M[c * K + r] = re;                         /* A */
+      M[(r + nn) * K + (c + nn)] = M[(c + nn) * K + (r + nn)] = re;
+      M[(r + nn) * K + c] = M[c * K + (r + nn)] = im;           /* B[r][c] =  im */
+      M[(c + nn) * K + r] = M[r * K + (c + nn)] = -im;          /* B[c][r] = -im */
+    }
+  }
+  psd_part_full(M, K);
+  for (c = 0; c < nn; ++c) {
+    double *col = X + c * (2 * nn - c);
+    col[0] = M[c * K + c] / sqrt2;
+    for (r = c + 1; r < nn; ++r) {
+      col[1 + 2 * (r - c - 1)] = M[r * K + c];
+      col[2 + 2 * (r - c - 1)] = M[(r + nn) * K + c];
+    }
+  }
+  free(M);
+}
+
+/* ---- exponential cone: src/exp_cone.c:373-441 `proj_pd_exp_cone` (Friberg 2021: heuristic
+ * primal / polar points, optimality shortcut, bracket, damped Newton + bisection on h(rho)) ---- */
+#define EXP_INF 1e15
+static int ex_finite(double x) { return fabs(x) < EXP_INF; }
+static double ex_clip(double x, double l, double u) { return MAXV(l, MINV(u, x)); }
+static double ex_safediv(double x, double y) { return y < 1e-18 ? x / 1e-18 : x / y; }
+static double ex_dist_sq(const double *a, const double *b) {
+  const double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+  return d0 * d0 + d1 * d1 + d2 * d2;
+}
+static void ex_h(const double *v0, double rho, double *f, double *df) { /* exp_cone.c:41-64 */
+  const double t0 = v0[2], s0 = v0[1], r0 = v0[0];
+  const double er = exp(rho), enr = 1.0 / er;
+  *f = ((rho - 1) * r0 + s0) * er - (r0 - rho * s0) * enr - (rho * (rho - 1) + 1) * t0;
+  if (df) *df = (rho * r0 + s0) * er + (r0 - (rho - 1) * s0) * enr - (2 * rho - 1) * t0;
+}
+static double ex_bisect(const double *v0, double xl, double xu, double x) { /* :67-98 */
+  double xp = x, f;
+  int i;
+  for (i = 0; i < 40; ++i) {
+    ex_h(v0, x, &f, NULL);
+    if (f < 0.0) xl = x;
+    else xu = x;
+    xp = 0.5 * (xl + xu);
+    if (fabs(xp - x) <= 1e-12 * MAXV(1.0, fabs(xp)) || xp == xl || xp == xu) break;
+    x = xp;
+  }
+  return xp;
+}
+static double ex_newton(const double *v0, double xl, double xu, double x) { /* :101-157 */
+  double xp, f, df;
+  int i;
+  for (i = 0; i < 20; ++i) {
+    ex_h(v0, x, &f, &df);
+    if (fabs(f) <= 1e-15) break;
+    if (f < 0.0) xl = x;
+    else xu = x;
+    if (xu <= xl) {
+      xu = 0.5 * (xu + xl);
+      xl = xu;
+      break;
+    }
+    if (!ex_finite(f) || df < 1e-13) break;
+    xp = x - f / df;
+    if (fabs(xp - x) <= 1e-15 * MAXV(1.0, fabs(xp))) break;
+    if (xp >= xu) x = MINV(0.05 * x + 0.95 * xu, xu);
+    else if (xp <= xl) x = MAXV(0.05 * x + 0.95 * xl, xl);
+    else x = xp;
+  }
+  if (i < 20) return ex_clip(x, xl, xu);
+  return ex_bisect(v0, xl, xu, x);
+}
+static double ex_heur_primal(const double *v0, double *vp) { /* :160-182 */
+  const double t0 = v0[2], s0 = v0[1], r0 = v0[0];
+  double d;
+  vp[2] = MAXV(t0, 0.0); vp[1] = 0; vp[0] = MINV(r0, 0.0);
+  d = ex_dist_sq(v0, vp);
+  if (s0 > 0.0) {
+    const double tp = MAXV(t0, s0 * exp(r0 / s0)), nd = (tp - t0) * (tp - t0);
+    if (nd < d) { vp[2] = tp; vp[1] = s0; vp[0] = r0; d = nd; }
+  }
+  return d;
+}
+static double ex_heur_polar(const double *v0, double *vd) { /* :185-207 */
+  const double t0 = v0[2], s0 = v0[1], r0 = v0[0];
+  double d;
+  vd[2] = MINV(t0, 0.0); vd[1] = MINV(s0, 0.0); vd[0] = 0;
+  d = ex_dist_sq(v0, vd);
+  if (r0 > 0.0) {
+    const double td = MINV(t0, -r0 * exp(s0 / r0 - 1.0)), nd = (t0 - td) * (t0 - td);
+    if (nd < d) { vd[2] = td; vd[1] = s0; vd[0] = r0; d = nd; }
+  }
+  return d;
+}
+static double ex_ppsi(const double *v0) { /* :209-220 */
+  const double s0 = v0[1], r0 = v0[0], q = sqrt(r0 * r0 + s0 * s0 - r0 * s0);
+  const double psi = r0 > s0 ? (r0 - s0 + q) / r0 : -s0 / (r0 - s0 - q);
+  return ((psi - 1.0) * r0 + s0) / (psi * (psi - 1.0) + 1.0);
+}
+static double ex_pomega(double rho) { /* :222-229 */
+  double v = exp(rho) / (rho * (rho - 1.0) + 1.0);
+  if (rho < 2.0) v = MINV(v, exp(2.0) / 3.0);
+  return v;
+}
+static double ex_dpsi(const double *v0) { /* :231-242 */
+  const double s0 = v0[1], r0 = v0[0], q = sqrt(r0 * r0 + s0 * s0 - r0 * s0);
+  const double psi = s0 > r0 ? (r0 - q) / s0 : (r0 - s0) / (r0 + q);
+  return (r0 - psi * s0) / (psi * (psi - 1.0) + 1.0);
+}
+static double ex_domega(double rho) { /* :244-251 */
+  double v = -exp(-rho) / (rho * (rho - 1.0) + 1.0);
+  if (rho > -1.0) v = MAXV(v, -exp(1.0) / 3.0);
+  return v;
+}
+static void ex_bracket(const double *v0, double pd, double dd, double *lo, double *up) { /* :254-317 */
+  const double t0 = v0[2], s0 = v0[1], r0 = v0[0];
+  double baselow = -EXP_INF, baseupr = EXP_INF, low = -EXP_INF, upr = EXP_INF;
+  const double ms = MINV(s0, 0.0), mr = MINV(r0, 0.0);
+  const double Dp = sqrt(MAXV(pd - ms * ms, 0.0)), Dd = sqrt(MAXV(dd - mr * mr, 0.0));
+  if (t0 > 0.0) low = MAXV(low, log(t0 / ex_ppsi(v0)));
+  else if (t0 < 0.0) upr = MINV(upr, -log(-t0 / ex_dpsi(v0)));
+  if (r0 > 0.0) {
+    double tpu, val, sgn;
+    baselow = 1.0 - s0 / r0;
+    low = MAXV(low, baselow);
+    tpu = MAXV(1e-12, MINV(Dd, Dp + t0));
+    val = r0 * ex_pomega(low);
+    sgn = val < 0 ? -1.0 : 1.0;
+    upr = MINV(upr, MAXV(low, baselow + ex_safediv(tpu, fabs(val)) * sgn));
+  }
+  if (s0 > 0.0) {
+    double tdl, val, sgn;
+    baseupr = r0 / s0;
+    upr = MINV(upr, baseupr);
+    tdl = -MAXV(1e-12, MINV(Dp, Dd - t0));
+    val = s0 * ex_domega(upr);
+    sgn = val < 0 ? -1.0 : 1.0;
+    low = MAXV(low, MINV(upr, baseupr - ex_safediv(tdl, fabs(val)) * sgn));
+  }
+  low = ex_clip(MINV(low, upr), baselow, baseupr);
+  upr = ex_clip(MAXV(low, upr), baselow, baseupr);
+  if (low != upr) {
+    double fl, fu;
+    ex_h(v0, low, &fl, NULL);
+    ex_h(v0, upr, &fu, NULL);
+    if (fl * fu > 0.0) {
+      if (fabs(fl) < fabs(fu)) upr = low;
+      else low = upr;
+    }
+  }
+  *lo = low;
+  *up = upr;
+}
+static double ex_sol_primal(const double *v0, double rho, double *vp) { /* :320-342 */
+  const double lin = (rho - 1.0) * v0[0] + v0[1], er = exp(rho);
+  if (lin > 0.0 && ex_finite(er)) {
+    const double q = rho * (rho - 1.0) + 1.0;
+    vp[2] = er * lin / q; vp[1] = lin / q; vp[0] = rho * lin / q;
+    return ex_dist_sq(vp, v0);
+  }
+  vp[2] = EXP_INF; vp[1] = 0; vp[0] = 0;
+  return EXP_INF;
+}
+static double ex_sol_polar(const double *v0, double rho, double *vd) { /* :345-367 */
+  const double lin = v0[0] - rho * v0[1], er = exp(-rho);
+  if (lin > 0.0 && ex_finite(er)) {
+    const double q = rho * (rho - 1.0) + 1.0;
+    vd[2] = -er * lin / q; vd[1] = (1.0 - rho) * lin / q; vd[0] = lin / q;
+    return ex_dist_sq(v0, vd);
+  }
+  vd[2] = -EXP_INF; vd[1] = 0; vd[0] = 0;
+  return EXP_INF;
+}
+static void cone_exp(double *v0, int primal) { /* exp_cone.c:373-441 */
+  const double TOL = 1e-8;
+  double vp[3], vd[3], vh[3], xl, xh, pd, dd, err;
+  int opt, i;
+  if (!primal) for (i = 0; i < 3; ++i) v0[i] = -v0[i];
+  pd = ex_heur_primal(v0, vp);
+  dd = ex_heur_polar(v0, vd);
+  err = fabs(vp[0] + vd[0] - v0[0]);
+  err = MAXV(err, fabs(vp[1] + vd[1] - v0[1]));
+  err = MAXV(err, fabs(vp[2] + vd[2] - v0[2]));
+  opt = v0[1] <= 0.0 && v0[0] <= 0.0;
+  opt = opt || MINV(pd, dd) <= TOL * TOL;
+  opt = opt || (err <= TOL && (vp[0] * vd[0] + vp[1] * vd[1] + vp[2] * vd[2]) <= TOL);
+  if (!opt) {
+    double rho;
+    ex_bracket(v0, pd, dd, &xl, &xh);
+    rho = ex_newton(v0, xl, xh, 0.5 * (xl + xh));
+    if (primal) {
+      if (ex_sol_primal(v0, rho, vh) <= pd) memcpy(vp, vh, sizeof vp);
+    } else {
+      if (ex_sol_polar(v0, rho, vh) <= dd) memcpy(vd, vh, sizeof vd);
+    }
+  }
+  if (primal) memcpy(v0, vp, sizeof vp);
+  else for (i = 0; i < 3; ++i) v0[i] = -vd[i]; /* polar -> dual */
+}
+
+/* ---- power cone: src/cones.c:1284-1335 (Newton on r, <= 20 steps) ---- */
+static double pw_x(double r, double xh, double rh, double a) {
+  const double x = 0.5 * (xh + sqrt(xh * xh + 4 * a * (rh - r) * r));
+  return MAXV(x, 1e-12);
+}
+static void cone_pow(double *v, double a) {
+  const double PTOL = 1e-9, xh = v[0], yh = v[1], rh = fabs(v[2]);
+  double x = 0, y = 0, r;
+  int i;
+  if (xh >= 0 && yh >= 0 && PTOL + pow(xh, a) * pow(yh, 1 - a) >= rh) return;
+  if (xh <= 0 && yh <= 0 && PTOL + pow(-xh, a) * pow(-yh, 1 - a) >= rh * pow(a, a) * pow(1 - a, 1 - a)) {
+    v[0] = v[1] = v[2] = 0;
+    return;
+  }
+  r = rh / 2;
+  for (i = 0; i < 20; ++i) {
+    double xa, y1a, f, dxdr, dydr, fp;
+    x = pw_x(r, xh, rh, a);
+    y = pw_x(r, yh, rh, 1 - a);
+    xa = pow(x, a);
+    y1a = pow(y, 1 - a);
+    f = xa * y1a - r;
+    if (fabs(f) < PTOL) break;
+    dxdr = a * (rh - 2 * r) / (2 * x - xh);
+    dydr = (1 - a) * (rh - 2 * r) / (2 * y - yh);
+    fp = xa * y1a * (a * dxdr / x + (1 - a) * dydr / y) - 1;
+    r = MAXV(r - f / fp, 0.0);
+    r = MINV(r, rh);
+  }
+  v[0] = x;
+  v[1] = y;
+  v[2] = v[2] < 0 ? -r : r;
 }
 
 struct OrCone {
   int m, z, l, bsize, qsize, ssize;
+  int cssize, ep, ed, psize; /* complex PSD, exponential (primal, dual), power cones */
+  int *cs;
+  double *pw;
   int *q, *s;
   double *bl, *bu; /* private, normalised copies */
   double box_t_warm_start;
@@ -368,8 +640,19 @@ OrCone *or_cone_init(int m, int z, int l, int bsize, const double *bl, const dou
   c->scratch = (double *)calloc(m > 0 ? m : 1, sizeof(double));
   return c;
 }
+/* the cones that follow the PSD blocks in the row order of cones.c:1340-1394: complex PSD,
+ * exponential (primal then dual, 3 rows each), power (3 rows each; negative parameter = dual) */
+void or_cone_set_extra(OrCone *c, int cssize, const int *cs, int ep, int ed, int psize, const double *pw) {
+  c->cssize = cssize; c->ep = ep; c->ed = ed; c->psize = psize;
+  free(c->cs); free(c->pw);
+  c->cs = (int *)calloc(cssize > 0 ? cssize : 1, sizeof(int));
+  c->pw = (double *)calloc(psize > 0 ? psize : 1, sizeof(double));
+  if (cssize) memcpy(c->cs, cs, cssize * sizeof(int));
+  if (psize) memcpy(c->pw, pw, psize * sizeof(double));
+}
 void or_cone_free(OrCone *c) {
   if (!c) return;
+  free(c->cs); free(c->pw);
   free(c->q); free(c->s); free(c->bl); free(c->bu); free(c->scratch);
   free(c);
 }
@@ -394,6 +677,26 @@ static void cone_proj_primal(OrCone *c, double *x, const double *r_y) {
   for (i = 0; i < c->ssize; ++i) {
     cone_psd(x + count, c->s[i]);
     count += c->s[i] * (c->s[i] + 1) / 2;
+  }
+  for (i = 0; i < c->cssize; ++i) {
+    cone_cpsd(x + count, c->cs[i]);
+    count += c->cs[i] * c->cs[i];
+  }
+  for (i = 0; i < c->ep + c->ed; ++i) {
+    cone_exp(x + count, i < c->ep);
+    count += 3;
+  }
+  for (i = 0; i < c->psize; ++i) {
+    double *v = x + count;
+    if (c->pw[i] >= 0) {
+      cone_pow(v, c->pw[i]);
+    } else { /* dual power cone through Moreau, cones.c:1427-1441 */
+      double w[3];
+      w[0] = -v[0]; w[1] = -v[1]; w[2] = -v[2];
+      cone_pow(w, -c->pw[i]);
+      v[0] += w[0]; v[1] += w[1]; v[2] += w[2];
+    }
+    count += 3;
   }
 }
 

@@ -24,6 +24,7 @@ long or_linsys_tot_cg_its(const OrLinSys *w);
 void or_linsys_free(OrLinSys *w);
 OrCone *or_cone_init(int m, int z, int l, int bsize, const double *bl, const double *bu, int qsize, const int *q,
                      int ssize, const int *s, const double *D);
+void or_cone_set_extra(OrCone *c, int cssize, const int *cs, int ep, int ed, int psize, const double *pw);
 void or_cone_proj_dual(OrCone *c, double *x, const double *r_y);
 void or_cone_free(OrCone *c);
 int or_solve(int m, int n, const int *Ap, const int *Ai, const double *Ax, const double *b, const double *c, int z,

@@ -38,16 +38,19 @@ def test_linsys_restatement_vs_golden_boundary_vectors():
 def test_cone_restatement_vs_golden():
     g = np.load(os.path.join(G, "cones.npz"))
     meta = json.load(open(os.path.join(G, "cones_meta.json")))
+    seen = set()
     for name, cone in meta.items():
-        if cone.get("ep") or cone.get("ed") or cone.get("p") or cone.get("cs"):
-            continue  # exp / power cones are outside the restatement's scope (golden-only, GPU tests)
+        seen.update(k for k in ("ep", "ed", "p", "cs", "s", "q", "bu") if cone.get(k))
         for variant in ("eucl", "ry"):
             x = g[f"{name}_{variant}_x"]
             want = g[f"{name}_{variant}_y"]
             r = g[f"{name}_{variant}_r"] if variant == "ry" else None
             got = pyoracle.oracle_proj_dual_cone(cone, x, r)
             err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
-            assert err <= (1e-11 if ("psd" in name or name == "mixed") else 1e-13), (name, variant, err)
+            tol = 1e-11 if ("psd" in name or name in ("mixed", "all", "all_c")) else 1e-12
+            assert err <= tol, (name, variant, err)
+    # the restatement covers every cone the fixtures hold: SOC, box, PSD, complex PSD, exp, dual exp, power
+    assert {"q", "bu", "s", "cs", "ep", "ed", "p"} <= seen, seen
 
 
 def _golden_solves():
