@@ -113,6 +113,10 @@ def restatement():
     lib.or_solve.restype = C.c_int
     lib.or_solve.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp,
                              C.c_int, _ip, C.c_int, _ip, C.POINTER(OrSettings), _dp, _dp, _dp, C.POINTER(OrInfo)]
+    lib.or_solve_ext.restype = C.c_int
+    lib.or_solve_ext.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                                 C.c_int, _ip, C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int, _dp,
+                                 C.POINTER(OrSettings), _dp, _dp, _dp, C.POINTER(OrInfo)]
     lib._bound = True
     return lib
 
@@ -184,6 +188,10 @@ def oracle_solve(prob, cg_tol_override=0.0, **over):
     z, l, bsize, bl, bu, q, s = _cone_args(prob.cone)
     x, y, sv = _np.zeros(prob.n), _np.zeros(prob.m), _np.zeros(prob.m)
     info = OrInfo()
-    lib.or_solve(prob.m, prob.n, _i(prob.Ap), _i(prob.Ai), _d(prob.Ax), _d(prob.b), _d(prob.c), z, l, bsize, _d(bl),
-                 _d(bu), len(q), _i(q), len(s), _i(s), C.byref(st), _d(x), _d(y), _d(sv), C.byref(info))
+    cs = _np.ascontiguousarray(prob.cone.get("cs", []), dtype=_np.int32)
+    pw = _np.ascontiguousarray(prob.cone.get("p", []), dtype=_np.float64)
+    lib.or_solve_ext(prob.m, prob.n, _i(prob.Ap), _i(prob.Ai), _d(prob.Ax), _d(prob.b), _d(prob.c), z, l, bsize,
+                     _d(bl), _d(bu), len(q), _i(q), len(s), _i(s), len(cs), _i(cs), int(prob.cone.get("ep", 0)),
+                     int(prob.cone.get("ed", 0)), len(pw), _d(pw), C.byref(st), _d(x), _d(y), _d(sv),
+                     C.byref(info))
     return dict(x=x, y=y, s=sv, info={k: getattr(info, k) for k, _ in OrInfo._fields_})

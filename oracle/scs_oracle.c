@@ -19,8 +19,8 @@
  * Cone PROJECTIONS: every cone the HIP path carries -- zero / nonneg / box / second-order /
  * PSD / complex PSD / exponential (primal, dual) / power (primal, dual); PSD and complex
  * PSD use a cyclic Jacobi eigensolver instead of LAPACK dsyevr / zheevr.  The whole-solve
- * restatement (or_solve) takes the zero / nonneg / box / SOC / PSD cones of the BASELINE
- * configs; the other cones' whole solves are checked against the real reference only.
+ * restatement takes the same set (or_solve: the BASELINE cone families; or_solve_ext: all of
+ * them) and walks the reference's trajectory on each (tests/test_oracle.py).
  */
 #include "scs_oracle.h"
 
@@ -721,9 +721,14 @@ static double apply_limit(double x) {
 }
 /* enforce_cone_boundaries (cones.c:366-379): how = 0 max |.|, 1 mean */
 static void enforce_boundaries(const OrCone *c, double *vec, int how) {
-  int count = c->z + c->l + c->bsize, i, j, nc = c->qsize + c->ssize;
-  for (i = 0; i < nc; ++i) {
-    int delta = i < c->qsize ? c->q[i] : c->s[i - c->qsize] * (c->s[i - c->qsize] + 1) / 2;
+  int count = c->z + c->l + c->bsize, i, j;
+  const int n3 = c->ep + c->ed + c->psize, nc = c->qsize + c->ssize + c->cssize + n3;
+  for (i = 0; i < nc; ++i) { /* set_cone_boundaries, cones.c:386-424: q, s(s+1)/2, cs^2, then 3-row cones */
+    int delta;
+    if (i < c->qsize) delta = c->q[i];
+    else if (i < c->qsize + c->ssize) delta = c->s[i - c->qsize] * (c->s[i - c->qsize] + 1) / 2;
+    else if (i < c->qsize + c->ssize + c->cssize) delta = c->cs[i - c->qsize - c->ssize] * c->cs[i - c->qsize - c->ssize];
+    else delta = 3;
     double w = 0;
     if (how == 0) w = v_norm_inf(vec + count, delta);
     else if (delta > 0) {
@@ -852,6 +857,15 @@ static void or_residuals(int m, int n, const int *Ap, const int *Ai, const doubl
 int or_solve(int m, int n, const int *Ap, const int *Ai, const double *Ax_in, const double *b_in, const double *c_in,
              int z, int l, int bsize, const double *bl, const double *bu, int qsize, const int *q, int ssize,
              const int *s, const OrSettings *st, double *xo, double *yo, double *so, OrInfo *info) {
+  return or_solve_ext(m, n, Ap, Ai, Ax_in, b_in, c_in, z, l, bsize, bl, bu, qsize, q, ssize, s, 0, NULL, 0, 0, 0, NULL,
+                      st, xo, yo, so, info);
+}
+
+/* the same loop over every cone type (complex PSD, exponential, power after the PSD blocks) */
+int or_solve_ext(int m, int n, const int *Ap, const int *Ai, const double *Ax_in, const double *b_in,
+                 const double *c_in, int z, int l, int bsize, const double *bl, const double *bu, int qsize,
+                 const int *q, int ssize, const int *s, int cssize, const int *cs, int ep, int ed, int psize,
+                 const double *pw, const OrSettings *st, double *xo, double *yo, double *so, OrInfo *info) {
   const int L = n + m + 1, nnz = Ap[n];
   int i, iter, status = 0, last_resid_iter = -1, last_scale_update_iter = 0, n_log = 0, scale_updates = 0;
   double sum_log = 0, scale = st->scale, sigma = 1.0, nm_b_orig, nm_c_orig;
@@ -876,6 +890,7 @@ int or_solve(int m, int n, const int *Ap, const int *Ai, const double *Ax_in, co
   for (i = 0; i < m; ++i) D[i] = 1.;
   for (i = 0; i < n; ++i) E[i] = 1.;
   cone = or_cone_init(m, z, l, bsize, bl, bu, qsize, q, ssize, s, NULL);
+  or_cone_set_extra(cone, cssize, cs, ep, ed, psize, pw);
   if (st->normalize) {
     double nb, nc;
     or_normalize_a(m, n, Ap, Ai, Ax, cone, D, E);
@@ -891,6 +906,7 @@ int or_solve(int m, int n, const int *Ap, const int *Ai, const double *Ax_in, co
     for (i = 0; i < m; ++i) b[i] *= sigma;
     or_cone_free(cone); /* box bounds pick up D on first projection (cones.c:1557-1565) */
     cone = or_cone_init(m, z, l, bsize, bl, bu, qsize, q, ssize, s, D);
+    or_cone_set_extra(cone, cssize, cs, ep, ed, psize, pw);
   }
 #define SET_DIAG_R()                                                                               \
   do { /* scs.c:971-980 + cones.c:349-363 */                                                       \

@@ -30,6 +30,10 @@ void or_cone_free(OrCone *c);
 int or_solve(int m, int n, const int *Ap, const int *Ai, const double *Ax, const double *b, const double *c, int z,
              int l, int bsize, const double *bl, const double *bu, int qsize, const int *q, int ssize, const int *s,
              const OrSettings *st, double *x, double *y, double *s_out, OrInfo *info);
+int or_solve_ext(int m, int n, const int *Ap, const int *Ai, const double *Ax, const double *b, const double *c,
+                 int z, int l, int bsize, const double *bl, const double *bu, int qsize, const int *q, int ssize,
+                 const int *s, int cssize, const int *cs, int ep, int ed, int psize, const double *pw,
+                 const OrSettings *st, double *x, double *y, double *s_out, OrInfo *info);
 #ifdef __cplusplus
 }
 #endif

@@ -133,3 +133,46 @@ def test_spmv_restatement_bitwise_vs_reference_kernel():
     lib.or_accum_by_atrans(100, prob.Ap.ctypes.data_as(T.ip), prob.Ai.ctypes.data_as(T.ip), prob.Ax.ctypes.data_as(T.fp),
                            x.ctypes.data_as(T.fp), y2.ctypes.data_as(T.fp))
     assert np.abs(y1 - y2).max() <= 4e-16 * np.abs(y1).max()
+
+
+@pytest.mark.skipif(not pyoracle.ref_available("libscsindir_ref_exactcg.so"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_all_cone_restatement_trajectory_equals_reference_with_exact_cg(seed):
+    """The whole-solve restatement over EVERY cone type (box, SOC, PSD, complex PSD, exponential,
+    dual exponential, power, dual power) walks the reference's trajectory when both solve the
+    linear systems to the 1e-12 floor.  The program is feasible and bounded by the reference
+    generator's construction, with the reference's own projection (test/problem_utils.h:43-56)."""
+    import ctypes as C
+    import scipy.sparse as sp
+    ref = pyoracle.load_ref("libscsindir_ref_exactcg.so")
+    T = capi.T64
+    rng = np.random.default_rng(300 + seed)
+    cone = dict(z=3, l=6, bu=[1.0, 2.0], bl=[-1.0, -0.5], q=[4, 7], s=[3, 5], cs=[3], ep=2, ed=2, p=[0.4, -0.7])
+    m = capi.cone_rows(cone)
+    n = m // 3
+    k = capi.make_cone(cone)
+    ref._scs_init_cone.restype = C.c_void_p
+    ref._scs_init_cone.argtypes = [C.POINTER(T.ScsCone), C.c_int]
+    ref._scs_proj_dual_cone.argtypes = [T.fp, C.c_void_p, C.c_void_p, T.fp]
+    ref._scs_finish_cone.argtypes = [C.c_void_p]
+    z = rng.standard_normal(m)
+    y = z.copy()
+    w = ref._scs_init_cone(C.byref(k), m)
+    assert ref._scs_proj_dual_cone(y.ctypes.data_as(T.fp), w, None, None) == 0
+    ref._scs_finish_cone(w)
+    # the restatement's projection agrees with the reference's on this very vector
+    assert np.abs(pyoracle.oracle_proj_dual_cone(cone, z) - y).max() <= 1e-10 * max(1.0, np.abs(y).max())
+    s = y - z
+    x = rng.standard_normal(n)
+    A = sp.random(m, n, density=min(1.0, 5.0 / n), random_state=seed, format="csc", data_rvs=rng.standard_normal)
+    A = (A + sp.csc_matrix((np.full(n, 0.7), (np.arange(n), np.arange(n))), shape=(m, n))).tocsc()
+    prob = capi.Problem(A, A @ x + s, -(A.T @ y), cone)
+    kw = dict(eps_abs=1e-5, eps_rel=1e-5, max_iters=30000)
+    rr = capi.solve(ref, prob, verbose=0, acceleration_lookback=0, **kw)
+    ro = pyoracle.oracle_solve(prob, cg_tol_override=1e-12, **kw)
+    assert rr["info"]["status_val"] == ro["info"]["status_val"] == 1
+    assert ro["info"]["iter"] == rr["info"]["iter"]
+    assert ro["info"]["scale_updates"] == rr["info"]["scale_updates"]
+    for key in ("pobj", "dobj", "res_pri", "res_dual", "gap", "scale"):
+        assert abs(ro["info"][key] - rr["info"][key]) <= 1e-6 * max(abs(rr["info"][key]), 1e-3), key
+    assert np.abs(ro["x"] - rr["x"]).max() <= 1e-6 * max(1.0, np.abs(rr["x"]).max())
