@@ -258,3 +258,33 @@ def test_concurrent_solves_from_several_host_threads_with_cg_graphs():
             assert a["info"]["status_val"] == b["info"]["status_val"]
             assert a["info"]["iter"] == b["info"]["iter"]
             assert np.array_equal(a["x"], b["x"])
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_all_cone_types_exact_cg_trajectory_equals_the_restatement(seed):
+    """Every cone type in one program (box, SOC, PSD, complex PSD, exponential and power, primal and
+    dual): with exact CG the HIP solve walks the same trajectory as the plain-C restatement, which
+    tests/test_oracle.py pins to the reference's on this same family."""
+    import scipy.sparse as sp
+    from oracle import pyoracle
+    amd = capi.load("libscsamd.so")
+    rng = np.random.default_rng(300 + seed)
+    cone = dict(z=3, l=6, bu=[1.0, 2.0], bl=[-1.0, -0.5], q=[4, 7], s=[3, 5], cs=[3], ep=2, ed=2, p=[0.4, -0.7])
+    m = capi.cone_rows(cone)
+    n = m // 3
+    z = rng.standard_normal(m)
+    y = pyoracle.oracle_proj_dual_cone(cone, z)
+    s = y - z
+    x = rng.standard_normal(n)
+    A = sp.random(m, n, density=min(1.0, 5.0 / n), random_state=seed, format="csc", data_rvs=rng.standard_normal)
+    A = (A + sp.csc_matrix((np.full(n, 0.7), (np.arange(n), np.arange(n))), shape=(m, n))).tocsc()
+    prob = capi.Problem(A, A @ x + s, -(A.T @ y), cone)
+    kw = dict(eps_abs=1e-5, eps_rel=1e-5, max_iters=30000)
+    ra = capi.solve(amd, prob, verbose=0, acceleration_lookback=0, cg_tol_override=1e-12, **kw)
+    ro = pyoracle.oracle_solve(prob, cg_tol_override=1e-12, **kw)
+    assert ra["info"]["status_val"] == ro["info"]["status_val"] == 1
+    assert ra["info"]["iter"] == ro["info"]["iter"]
+    assert ra["info"]["scale_updates"] == ro["info"]["scale_updates"]
+    for key in ("pobj", "dobj", "res_pri", "res_dual", "gap", "scale"):
+        assert abs(ra["info"][key] - ro["info"][key]) <= 1e-6 * max(abs(ro["info"][key]), 1e-3), key
+    assert np.abs(ra["x"] - ro["x"]).max() <= 1e-6 * max(1.0, np.abs(ro["x"]).max())
