@@ -231,7 +231,7 @@ def main():
         spmv_ms = stats1.spmv_ms - stats0.spmv_ms
         bytes_per_spmv = stats1.spmv_bytes / 2.0  # already computed with sizeof(scs_float) of the library
         roof = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                    kernel="csr_sliced_kernel / csr_stream_kernel (CSR SpMV, both orientations)")
+                    kernel="csr_wave_kernel (wave-owned rows CSR SpMV, both orientations)")
         if spmv_samples > 0 and spmv_ms > 0:
             avg_s = spmv_ms / spmv_samples * 1e-3
             roof["achieved"] = bytes_per_spmv / avg_s / 1e9

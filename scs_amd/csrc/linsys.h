@@ -5,7 +5,7 @@
 #pragma once
 #include "spmv.h"
 #include "scs_host.h"
-#include "spmv_sliced.h"
+#include "spmv_wave.h"
 
 namespace scsamd {
 

@@ -25,9 +25,10 @@ constexpr long long CG_GRAPH_MAX_NNZ = 2000000; // systems up to this many nonze
 
 
 constexpr int VEC_MAX_GRID = 512; // every consumer workgroup re-reduces the producers' partials: 2048 WGs cost K4 64 MB of L2 reads (measured 2.5 % of a CG iteration)
-constexpr int PART_CAP = SL_MAX_GRID; // >= SPMV_MAX_GRID, >= SL_MAX_GRID and >= 2 * VEC_MAX_GRID
+constexpr int PART_CAP = 4096; // >= SPMV_MAX_GRID, >= WR_MAX_GRID and >= 2 * VEC_MAX_GRID
+static_assert(PART_CAP >= SPMV_MAX_GRID && PART_CAP >= WR_MAX_GRID && PART_CAP >= 2 * 512, "partial arrays too small");
 
-CsrDev::~CsrDev() { delete sliced; }
+CsrDev::~CsrDev() { delete wave; }
 
 static inline int vec_grid(long long len) {
   static const int cap = [] {
@@ -398,17 +399,17 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
   int slot = -1;
   const bool sample = profiling && ((spmv_sample_ctr++ & 7) == 0);
   if (sample) slot = spmv_timer.start(stream);
-  if (mat.sliced && mat.sliced->built) {
-    const SlicedDev &sd = *mat.sliced;
-    const int g = sd.grid();
-    const size_t lds = sd.lds_bytes();
-    SlicedView v = sd.view();
+  if (mat.wave && mat.wave->built) {
+    const WaveRowsDev &wd = *mat.wave;
+    const int g = wd.grid();
+    const size_t lds = wd.lds_bytes();
+    WaveView v = wd.view();
     switch (epi) {
-    case EPI_PLAIN: hipLaunchKernelGGL(csr_sliced_kernel<EPI_PLAIN>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
-    case EPI_DIV: hipLaunchKernelGGL(csr_sliced_kernel<EPI_DIV>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
-    case EPI_GP: hipLaunchKernelGGL(csr_sliced_kernel<EPI_GP>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
-    case EPI_ACC: hipLaunchKernelGGL(csr_sliced_kernel<EPI_ACC>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
-    case EPI_NEGDIV: hipLaunchKernelGGL(csr_sliced_kernel<EPI_NEGDIV>, dim3(g), dim3(SCSAMD_BLOCK), lds, stream, v, x, y, e, skip, sd.accrows); break;
+    case EPI_PLAIN: hipLaunchKernelGGL(csr_wave_kernel<EPI_PLAIN>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
+    case EPI_DIV: hipLaunchKernelGGL(csr_wave_kernel<EPI_DIV>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
+    case EPI_GP: hipLaunchKernelGGL(csr_wave_kernel<EPI_GP>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
+    case EPI_ACC: hipLaunchKernelGGL(csr_wave_kernel<EPI_ACC>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
+    case EPI_NEGDIV: hipLaunchKernelGGL(csr_wave_kernel<EPI_NEGDIV>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
     default: throw HipError("scs_amd: bad spmv epilogue");
     }
     if (sample) spmv_timer.stop(slot, stream);
@@ -473,10 +474,10 @@ void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s,
   // CSC(A) is CSR(A'): upload as is
   At.upload(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
   phase("upload At");
-  if (SlicedDev::wanted(m, A_csc->p, n)) {
-    At.sliced = new SlicedDev();
-    At.sliced->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
-    phase("sliced At");
+  if (WaveRowsDev::wanted(m, A_csc->p, n)) {
+    At.wave = new WaveRowsDev();
+    At.wave->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+    phase("wave-rows At");
   }
   {
     std::vector<int> Cp_own, Ci_own;
@@ -493,10 +494,10 @@ void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s,
     phase("transpose");
     A.upload(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
     phase("upload A");
-    if (SlicedDev::wanted(n, Cp.data(), m)) {
-      A.sliced = new SlicedDev();
-      A.sliced->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
-      phase("sliced A");
+    if (WaveRowsDev::wanted(n, Cp.data(), m)) {
+      A.wave = new WaveRowsDev();
+      A.wave->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
+      phase("wave-rows A");
     }
   }
   has_P = P_csc != nullptr;
@@ -620,7 +621,7 @@ void LinSys::harvest_timers() {
 void LinSys::enqueue_cg_iteration(int q) {
   CgCtl *c = ctl.p;
   const int gv = vec_grid(n);
-  const int gAt = (At.sliced && At.sliced->built) ? At.sliced->grid() : At.grid();
+  const int gAt = (At.wave && At.wave->built) ? At.wave->grid() : At.grid();
   real *part_pgp = partA.p, *part_ztr = partB.p, *part_max = partB.p + PART_CAP / 2;
   EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
   launch_spmv(EPI_DIV, A, p.p, tmp.p, e1, &c->cg_done);

@@ -136,9 +136,9 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, con
 #endif // __HIPCC__
 
 // ---- device-resident CSR with its row-block table ---------------------------
-struct SlicedDev;
+struct WaveRowsDev;
 struct CsrDev {
-  SlicedDev *sliced = nullptr; // owned; built by LinSys::init when SlicedDev::wanted()
+  WaveRowsDev *wave = nullptr; // owned; built by LinSys::init when WaveRowsDev::wanted()
   ~CsrDev();
   CsrDev() = default;
   CsrDev(const CsrDev &) = delete;

@@ -1,0 +1,197 @@
+// spmv_wave.h -- "wave-owned rows" CSR product for gather vectors that do not fit a 4 MB XCD L2
+// (same results and epilogues as csr_stream_kernel in spmv.h; replaces round 1's column-sliced
+// kernel).  Replaces SCS(accum_by_atrans), reference linsys/scs_matrix.c:161-186.
+//
+// Why: on the headline config the product is bound by the scattered 8-byte reads of x, each of
+// which moves a whole 128-byte line from L2 to the CU (lab/spmv_lab.hip: 1e7 such reads take
+// 37 us L2-resident, 80 us from an 8 MB table, 111 us from 16 MB; profiles/r2_spmv_lab.md), and
+// round 1's kernel added a load -> gather -> LDS -> barrier -> segmented sum -> barrier chain per
+// 512 products on top of that.
+//
+// How: a *wave* owns a unit of <= 1024 consecutive rows and keeps one accumulator per row in a
+// private slice of LDS.  It streams the unit's entries -- val (8 B) + one packed word
+// (column | local row << cbits) = the same 12 B/nnz as CSR and no row pointers -- with unit
+// stride, gathers x[column] and adds val * x to its accumulator with an LDS atomic
+// (ds_add_f64 / ds_add_f32).  A wave's LDS operations execute in program order and nothing else
+// touches its accumulators, so there is no barrier, no product staging and no sort in the
+// kernel, and the sum is reproducible bit for bit.  Inside a unit the entries are stored by
+// ascending column bucket; all waves are resident at once and start together, so at any moment
+// the whole chip gathers from one window of x that moves upwards and stays in every XCD's L2
+// (measured 91 % L2 hits on the gathers, profiles/r2_g2_lab_pmc.md).  Units are balanced by
+// nonzeros (about 8 waves per CU: fewer, fatter waves measured faster than many thin ones).
+// Summation order inside a row is column-bucket order with row-major ties (rounding-level
+// difference from the reference's index order).
+// Measured (lab/g2_lab.hip, headline shapes): 54-56 us (A) / 59 us (A') vs 62-65 us for the
+// sliced kernel in the same harness.
+#pragma once
+#include "spmv.h"
+#include <algorithm>
+
+namespace scsamd {
+
+constexpr int WR_WPB = 4;           // waves per workgroup (one unit each)
+constexpr int WR_BLOCK = WR_WPB * 64;
+constexpr int WR_ROWS_MAX = 1024;   // rows per unit (8 KB of fp64 accumulators per wave)
+constexpr int WR_MAX_GRID = 4096;   // partial-array bound for the fused dot product
+constexpr int WR_BUCKETS = 1024;    // column buckets per unit (ordering heuristic only)
+
+struct WaveView {
+  int rows, nunit, cbits;
+  const int *urow;     // nunit + 1 : first row of each unit
+  const int *useg;     // 2 * nunit : [first entry (4-aligned), one past the last entry] of each unit
+  const unsigned *wrd; // nnz : column | local row << cbits
+  const real *val;     // nnz
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void lds_add(real *p, real v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
+                                                            const int *skip, int accrows) {
+  if (skip && *skip) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wr_smem[];
+  __shared__ real red[WR_WPB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  real *acc = reinterpret_cast<real *>(wr_smem) + (size_t)wave * accrows;
+  const unsigned cmask = (1u << A.cbits) - 1;
+  real dot = 0;
+  for (int u = blockIdx.x * WR_WPB + wave; u < A.nunit; u += gridDim.x * WR_WPB) {
+    const int r0 = A.urow[u], nr = A.urow[u + 1] - r0;
+    const int s = A.useg[2 * u], t = A.useg[2 * u + 1];
+    for (int k = lane; k < nr; k += 64) acc[k] = 0;
+    // a lane owns 4 consecutive entries of every 256-entry chunk: one 16-byte load of packed words and
+    // 16-byte loads of values (3 stream instructions per chunk instead of 8; unit starts are 4-aligned)
+    for (int e0 = s; e0 < t; e0 += 256) {
+      const int eb = e0 + lane * 4;
+      const uint4 wq = *reinterpret_cast<const uint4 *>(A.wrd + eb);
+      real v[4];
+      if (sizeof(real) == 8) {
+        const double2 va = *reinterpret_cast<const double2 *>(A.val + eb), vb = *reinterpret_cast<const double2 *>(A.val + eb + 2);
+        v[0] = (real)va.x; v[1] = (real)va.y; v[2] = (real)vb.x; v[3] = (real)vb.y;
+      } else {
+        const float4 va = *reinterpret_cast<const float4 *>(A.val + eb);
+        v[0] = (real)va.x; v[1] = (real)va.y; v[2] = (real)va.z; v[3] = (real)va.w;
+      }
+      const unsigned w[4] = {wq.x, wq.y, wq.z, wq.w};
+      real xx[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xx[i] = eb + i < t ? x[w[i] & cmask] : (real)0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (eb + i < t) lds_add(acc + (w[i] >> A.cbits), v[i] * xx[i]);
+    }
+    for (int k = lane; k < nr; k += 64) {
+      const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
+      epi_apply<EPI>(e, y, r0 + k, a, dot);
+    }
+  }
+  if (EPI == EPI_GP && e.partial) {
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      real sum = red[0];
+      for (int i = 1; i < WR_WPB; ++i) sum += red[i];
+      e.partial[blockIdx.x] = sum;
+    }
+  }
+}
+#endif // __HIPCC__
+
+struct WaveRowsDev {
+  bool built = false;
+  int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0;
+  DevBuf<int> urow, useg;
+  DevBuf<unsigned> wrd;
+  DevBuf<real> val;
+  WaveView view() const { return WaveView{rows, nunit, cbits, urow.p, useg.p, wrd.p, val.p}; }
+  int grid() const { return std::max(1, std::min((nunit + WR_WPB - 1) / WR_WPB, WR_MAX_GRID)); }
+  size_t lds_bytes() const { return (size_t)WR_WPB * accrows * sizeof(real); }
+  static int col_bits(int cols) {
+    int b = 1;
+    while ((1ll << b) < cols) ++b;
+    return b;
+  }
+  // worth it only when the gathered vector overflows an XCD's L2 (below that csr_stream's gathers
+  // are L2 hits anyway) and there are enough nonzeros to fill the chip
+  static bool wanted(int cols, const int *hptr, int rows) {
+    if (col_bits(cols) > 26) return false; // packed word: column bits + at least 6 row bits
+    if (const char *e = getenv("SCS_AMD_WAVEROWS")) return atoi(e) != 0; // tests force either path
+    if ((size_t)cols * sizeof(real) <= (size_t)3 << 20) return false;
+    return (long long)hptr[rows] >= 4000000LL;
+  }
+  void build(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval, hipStream_t st) {
+    rows = rows_;
+    cols = cols_;
+    cbits = col_bits(cols);
+    const int rows_cap = (int)std::min<long long>(WR_ROWS_MAX, 1ll << (32 - cbits));
+    const long long nnz_all = hptr[rows];
+    // nonzero budget per unit: ~8 waves per CU on the whole chip (SCS_AMD_WR_NNZ overrides)
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long budget = std::max<long long>(1024, (nnz_all + 8LL * cus - 1) / (8LL * cus));
+    if (const char *e = getenv("SCS_AMD_WR_NNZ")) budget = std::max(64, atoi(e));
+    std::vector<int> ur, us;
+    ur.push_back(0);
+    int r = 0;
+    while (r < rows) {
+      const int s0 = r;
+      long long acc = 0;
+      while (r < rows && r - s0 < rows_cap) {
+        const long long rn = hptr[r + 1] - hptr[r];
+        if (acc + rn > budget && r > s0) break;
+        acc += rn;
+        ++r;
+      }
+      ur.push_back(r);
+    }
+    nunit = (int)ur.size() - 1;
+    us.resize((size_t)2 * nunit);
+    accrows = 2;
+    size_t q = 0; // unit starts are rounded up to 4 entries (16-byte vector loads); the gaps hold zeros
+    for (int u = 0; u < nunit; ++u) {
+      q = (q + 3) & ~(size_t)3;
+      us[2 * u] = (int)q;
+      q += (size_t)(hptr[ur[u + 1]] - hptr[ur[u]]);
+      us[2 * u + 1] = (int)q;
+      accrows = std::max(accrows, ur[u + 1] - ur[u]);
+    }
+    accrows = (accrows + 1) & ~1;
+    const size_t cap = q + 256 + 8; // the last chunk of a unit may read up to 255 entries past its end
+    if (cap >= ((size_t)1 << 31)) throw HipError("scs_amd: matrix too large for 32-bit entry offsets");
+    std::vector<unsigned> hw(cap, 0u);
+    std::vector<real> hv(cap, (real)0);
+    // stable counting sort of every unit by column bucket (ordering is a locality heuristic: any
+    // order gives the same sums up to rounding)
+    const int bshift = std::max(0, cbits - 10);
+    std::vector<int> cnt(WR_BUCKETS + 1);
+    for (int u = 0; u < nunit; ++u) {
+      const int k0 = hptr[ur[u]], k1 = hptr[ur[u + 1]];
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int k = k0; k < k1; ++k) cnt[(hidx[k] >> bshift) + 1]++;
+      for (int b = 0; b < WR_BUCKETS; ++b) cnt[b + 1] += cnt[b];
+      const size_t base = (size_t)us[2 * u];
+      for (int rr = ur[u]; rr < ur[u + 1]; ++rr)
+        for (int k = hptr[rr]; k < hptr[rr + 1]; ++k) {
+          const size_t qq = base + cnt[hidx[k] >> bshift]++;
+          hw[qq] = (unsigned)hidx[k] | ((unsigned)(rr - ur[u]) << cbits);
+          hv[qq] = hval[k];
+        }
+    }
+    urow.alloc(ur.size());
+    useg.alloc(us.size());
+    wrd.alloc(cap);
+    val.alloc(cap);
+    urow.upload(ur.data(), ur.size(), st);
+    useg.upload(us.data(), us.size(), st);
+    wrd.upload(hw.data(), cap, st);
+    val.upload(hv.data(), cap, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    built = true;
+  }
+};
+
+} // namespace scsamd

@@ -106,10 +106,14 @@ def test_with_P_matches_reference():
     ref.scs_free_lin_sys_work(wr)
 
 
-def test_sliced_spmv_path_equals_csr_stream_path(monkeypatch):
-    """The column-sliced kernel (spmv_sliced.h, used when the gathered vector overflows
-    L2) and the CSR-stream kernel solve the same system to the same answer."""
+def test_wave_rows_spmv_path_equals_reference_and_csr_stream_path(monkeypatch):
+    """The wave-owned-rows kernel (spmv_wave.h, used when the gathered vector overflows L2) forced on
+    at a size the reference backend solves in a second: same answer as the reference's own
+    linsys/cpu/indirect and as the CSR-stream kernel; small nonzero budgets force several units per
+    wave, single-row units and the grid-stride loop."""
     amd = capi.load("libscsamd_linsys.so")
+    from oracle import pyoracle
+    ref = pyoracle.load_ref() if pyoracle.ref_available() else None
     n, m = 30000, 70001
     rng = np.random.default_rng(9)
     A = probgen.random_csc(m, n, 7, seed=5)
@@ -118,9 +122,19 @@ def test_sliced_spmv_path_equals_csr_stream_path(monkeypatch):
     b = rng.uniform(-1, 1, n + m)
     s = rng.uniform(-1, 1, n)
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("SCS_AMD_SLICED", flag)
+    for flag, budget in (("0", None), ("1", None), ("1", "64"), ("1", "100000")):
+        monkeypatch.setenv("SCS_AMD_WAVEROWS", flag)
+        if budget:
+            monkeypatch.setenv("SCS_AMD_WR_NNZ", budget)
+        else:
+            monkeypatch.delenv("SCS_AMD_WR_NNZ", raising=False)
         w, out = _solve_with(amd, prob.matA, None, dr, b, s, 1e-12)
         amd.scs_free_lin_sys_work(w)
         outs.append(out)
-    assert np.abs(outs[0] - outs[1]).max() <= 1e-9 * np.abs(outs[0]).max()
+    for o in outs[1:]:
+        assert np.abs(outs[0] - o).max() <= 1e-9 * np.abs(outs[0]).max()
+    if ref is not None:
+        wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
+        ref.scs_free_lin_sys_work(wr)
+        for o in outs:
+            assert np.abs(o - xr).max() <= 1e-8 * np.abs(xr).max()
