@@ -241,6 +241,8 @@ typedef struct {
   long long cone_projs;
   long long nnz;             /* nnz(A)                                       */
   long long spmv_bytes;      /* algorithmic bytes of ONE mat_vec (2 SpMV)    */
+  long long psd_unconverged; /* PSD block projections whose Jacobi eigensolve hit the sweep cap (the
+                              * reference's LAPACK info > 0 case: reported, not fatal, src/cones.c:1031) */
 } ScsAmdStats;
 
 void scs_amd_linsys_get_stats(const ScsLinSysWork *w, ScsAmdStats *out);

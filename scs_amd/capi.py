@@ -80,6 +80,7 @@ def make_types(ftype):
             ("mat_vecs", C.c_longlong), ("spmv_launches", C.c_longlong),
             ("spmv_ms", C.c_double), ("cg_ms", C.c_double), ("cone_ms", C.c_double),
             ("cone_projs", C.c_longlong), ("nnz", C.c_longlong), ("spmv_bytes", C.c_longlong),
+            ("psd_unconverged", C.c_longlong),
         ]
 
     ns = type("ScsTypes", (), {})

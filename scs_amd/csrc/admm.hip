@@ -364,6 +364,7 @@ struct SCS_WORK {
   DevBuf<real> u, u_t, v, v_prev, rsk, g, diag_r, b, c, D, E, warm, cw, ax, aty, px;
   DevBuf<real> part, qout;
   PinnedBuf<real> hq;
+  long long psd_unconverged = 0;
   // residual / scale state
   Resid r_n, r_o;
   real sum_log_scale_factor = 0;
@@ -499,6 +500,12 @@ static void populate_residuals(ScsWork *w, int iter) {
   HIP_CHECK(hipMemcpyAsync(w->hq.p, w->qout.p, NQ * sizeof(real), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   w->cone_timer.harvest(); // stream is idle here
+  if (w->cone.n_psd > 0) { // the reference reports LAPACK info > 0 and carries on (src/cones.c:1031-1032, src/scs.c:1389)
+    const int bad = w->cone.take_status(st);
+    if (bad > 0 && w->psd_unconverged == 0 && w->stgs.verbose)
+      printf("WARNING: %d PSD block projection(s) hit the Jacobi sweep cap (eigenvalues may be inaccurate)\n", bad);
+    w->psd_unconverged += bad;
+  }
   const real *q = w->hq.p;
   Resid &r = w->r_n;
   r.last_iter = iter;
@@ -749,7 +756,6 @@ static int update_scale(ScsWork *w, int iter) { // :1164-1241
     w->ls.set_diag_r_dev(w->diag_r.p);
     update_work_cache(w);
     if (w->accel) aa_host_reset(w->accel);
-  if (w->accel_dev) aa_dev_reset(w->accel_dev);
     if (w->accel_dev) aa_dev_reset(w->accel_dev);
     hipLaunchKernelGGL(k_remap_v, dim3(glue_grid(w->l)), dim3(SCSAMD_BLOCK), 0, w->stream, w->v.p, w->rsk.p,
                        w->diag_r.p, w->u_t.p, w->u.p, w->l);
@@ -970,6 +976,7 @@ scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) { // src/scs.c:1287-1
   if (!w) return -1;
   const double t0 = now_ms();
   try {
+    HIP_CHECK(hipSetDevice(w->device));
     if (b) {
       if (w->b_orig.data() != b) std::copy(b, b + w->m, w->b_orig.begin());
       real nb = 0;
@@ -1010,9 +1017,10 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
   try {
     if (scs_amd_device_count() <= 0)
       throw HipError("scs_amd: no HIP device visible -- this backend has no CPU fallback");
-    HIP_CHECK(hipSetDevice(selected_device()));
+    const int dev = selected_device(); // snapshot once: another thread may re-select concurrently
+    HIP_CHECK(hipSetDevice(dev));
     w = new ScsWork();
-    w->device = selected_device();
+    w->device = dev;
     const int n = w->n = d->n, m = w->m = d->m, l = w->l = d->n + d->m + 1;
     w->stgs = *stgs;
     if (stgs->write_data_filename) { // src/scs.c:1272-1275
@@ -1450,7 +1458,11 @@ scs_int scs_amd_equilibrate(ScsMatrix *A, ScsMatrix *P, const ScsCone *k, scs_fl
   }
 }
 
-void scs_finish(ScsWork *w) { delete w; }
+void scs_finish(ScsWork *w) {
+  if (!w) return;
+  (void)hipSetDevice(w->device);
+  delete w;
+}
 
 scs_int scs(const ScsData *d, const ScsCone *k, const ScsSettings *stgs, ScsSolution *sol,
             ScsInfo *info) { // :1538-1551
@@ -1476,6 +1488,7 @@ void scs_amd_set_profiling(ScsWork *w, scs_int on) {
 void scs_amd_get_stats(const ScsWork *cw, ScsAmdStats *out) {
   if (!cw || !out) return;
   ScsWork *w = const_cast<ScsWork *>(cw);
+  (void)hipSetDevice(w->device);
   (void)hipStreamSynchronize(w->stream);
   w->ls.harvest_timers();
   memset(out, 0, sizeof *out);
@@ -1489,6 +1502,7 @@ void scs_amd_get_stats(const ScsWork *cw, ScsAmdStats *out) {
   out->cone_projs = w->cone_timer.samples;
   out->nnz = w->ls.A.nnz;
   out->spmv_bytes = w->ls.matvec_bytes();
+  out->psd_unconverged = w->psd_unconverged;
 }
 
 } // extern "C"

@@ -41,17 +41,28 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 }
 #define HIP_CHECK(x) ::scsamd::hip_check((x), #x, __FILE__, __LINE__)
 
-// one zero-fill stream per host thread (re-created if the thread switches device), never destroyed
+// one zero-fill stream per host thread, owned by a thread_local holder: destroyed when the thread
+// exits and when the thread switches device
+struct FillStream {
+  hipStream_t st = nullptr;
+  int dev = -1;
+  ~FillStream() {
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
 inline hipStream_t fill_stream() {
-  static thread_local hipStream_t st = nullptr;
-  static thread_local int st_dev = -1;
+  static thread_local FillStream fs;
   int dev = 0;
   HIP_CHECK(hipGetDevice(&dev));
-  if (!st || st_dev != dev) {
-    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    st_dev = dev;
+  if (!fs.st || fs.dev != dev) {
+    if (fs.st) {
+      (void)hipStreamDestroy(fs.st); // queued fills complete first: hipStreamDestroy is asynchronous-safe
+      fs.st = nullptr;
+    }
+    HIP_CHECK(hipStreamCreateWithFlags(&fs.st, hipStreamNonBlocking));
+    fs.dev = dev;
   }
-  return st;
+  return fs.st;
 }
 
 // ---- device buffer (RAII) -------------------------------------------------

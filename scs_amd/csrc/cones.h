@@ -34,7 +34,8 @@ struct ConeDev {
   // exponential (primal, dual) and power cones: 3 rows each, after the PSD blocks
   int ep = 0, ed = 0, psize = 0, exp_off = 0;
   DevBuf<real> pow_a;       // psize power-cone parameters (negative = dual cone)
-  DevBuf<int> status;       // [0] != 0 if any projection failed
+  DevBuf<int> status;       // [0] = PSD block projections that hit the Jacobi sweep cap since the last take_status()
+  int take_status(hipStream_t st);
 
   // host staging for the B1' boundary
   DevBuf<real> x_stage, s_stage, r_stage;

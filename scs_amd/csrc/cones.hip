@@ -380,7 +380,9 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     // an off-diagonal entry at or below the convergence threshold is left alone; a step
     // whose pairs are all below it skips the update pass (and its barrier) altogether, so
     // the last, verifying sweep costs only the pair scan
-    const real thr = eps * fro / (real)k;
+    // fp32: entries cannot be driven below the rounding noise of the rotations themselves (~eps_mach |A|);
+    // a threshold under it would run all PSD_MAX_SWEEPS sweeps on every call
+    const real thr = sizeof(real) == 8 ? eps * fro / (real)k : fmaxf(eps * fro / (real)k, (real)2.4e-7 * fro);
     if (tid < 2) rot_any[tid] = 0;
     __syncthreads();
     for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       if (offmax <= thr) break;
     }
   }
-  if (sweep >= PSD_MAX_SWEEPS && tid == 0) atomicMax(status, 1); // did not converge (positive: not fatal)
+  if (sweep >= PSD_MAX_SWEEPS && tid == 0) atomicAdd(status, 1); // did not converge: counted, not fatal (cones.c:1031-1032)
   // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044); lambda = diag(A)
   __syncthreads();
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
@@ -543,8 +545,8 @@ long long cone_total_rows(const ScsCone *k) {
   return t;
 }
 
-// mirrors the checks of reference src/cones.c:583-700 (validate_cones) for the
-// cones carried here and REJECTS the ones that are not (complex PSD, exp, power)
+// mirrors the checks of reference src/cones.c:583-700 (validate_cones); every cone type of the default
+// reference build is carried (zero, nonneg, box, SOC, PSD, complex PSD, exp, dual exp, power)
 int validate_cone(const ScsCone *k, int m, bool verbose) {
 #define CONE_FAIL(msg)                                                                             \
   do {                                                                                             \
@@ -734,6 +736,15 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
   proj_exp_pow(cw);
 }
 
+// number of PSD block projections that hit the sweep cap since the last call; resets the device counter
+int ConeDev::take_status(hipStream_t st) {
+  int h = 0;
+  HIP_CHECK(hipMemcpyAsync(&h, status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (h) HIP_CHECK(hipMemsetAsync(status.p, 0, sizeof(int), st));
+  return h;
+}
+
 void ConeDev::proj_exp_pow(real *cw) {
   if (ep + ed + psize > 0)
     hipLaunchKernelGGL(k_exp_pow, dim3(small_grid(ep + ed + psize)), dim3(SCSAMD_BLOCK), 0, stream, cw + exp_off, ep, ed,
@@ -791,8 +802,9 @@ scs_int scs_amd_cone_proj_dual(ScsAmdConeWork *c, scs_float *x, const scs_float 
     if (r_y) cd.r_stage.upload(r_y, cd.m, c->stream);
     cd.proj_dual(cd.x_stage.p, cd.s_stage.p, r_y ? cd.r_stage.p : nullptr);
     cd.x_stage.download(x, cd.m, c->stream);
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    const int bad = cd.take_status(c->stream); // synchronises the stream
     HIP_CHECK(hipGetLastError());
+    if (bad > 0) return 1; // like LAPACK info > 0 in the reference: positive, not fatal (src/cones.c:1031-1032)
   } catch (const std::exception &ex) {
     fprintf(stderr, "%s\n", ex.what());
     return -1;

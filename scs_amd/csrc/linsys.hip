@@ -784,11 +784,17 @@ using namespace scsamd;
 
 struct SCS_LIN_SYS_WORK {
   LinSys ls;
+  int device = 0;
 };
 
-static int g_device = 0;
+// Device selection is per host thread (like HIP's own current device); a thread that never chose one
+// inherits the most recent choice of any thread.  Workspaces remember the device they were created on
+// and every entry point that takes one makes it current first.
+#include <atomic>
+static std::atomic<int> g_default_device{0};
+static thread_local int t_device = -1;
 namespace scsamd {
-int selected_device() { return g_device; }
+int selected_device() { return t_device >= 0 ? t_device : g_default_device.load(std::memory_order_relaxed); }
 }
 
 extern "C" {
@@ -801,7 +807,8 @@ scs_int scs_amd_device_count(void) {
 
 scs_int scs_amd_set_device(scs_int dev) {
   if (hipSetDevice(dev) != hipSuccess) return -1;
-  g_device = dev;
+  t_device = dev;
+  g_default_device.store(dev, std::memory_order_relaxed);
   return 0;
 }
 
@@ -811,8 +818,10 @@ ScsLinSysWork *scs_init_lin_sys_work(const ScsMatrix *A, const ScsMatrix *P, con
   if (!A || !diag_r) return nullptr;
   ScsLinSysWork *w = nullptr;
   try {
-    HIP_CHECK(hipSetDevice(g_device));
+    const int dev = selected_device(); // snapshot once: another thread may re-select concurrently
+    HIP_CHECK(hipSetDevice(dev));
     w = new ScsLinSysWork();
+    w->device = dev;
     w->ls.init(A, P, nullptr);
     w->ls.b_stage.alloc((size_t)A->n + A->m);
     w->ls.s_stage.alloc((size_t)A->n);
@@ -833,6 +842,7 @@ scs_int scs_solve_lin_sys(ScsLinSysWork *w, scs_float *b, const scs_float *s, sc
     printf("Warning: tol = %4f <= 0, likely compiled without setting INDIRECT flag.\n", (double)tol);
   }
   try {
+    HIP_CHECK(hipSetDevice(w->device));
     LinSys &ls = w->ls;
     const size_t n = ls.n, m = ls.m;
     ls.b_stage.upload(b, n + m, ls.stream);
@@ -850,6 +860,7 @@ scs_int scs_solve_lin_sys(ScsLinSysWork *w, scs_float *b, const scs_float *s, sc
 scs_int scs_update_lin_sys_diag_r(ScsLinSysWork *w, const scs_float *new_diag_r) {
   if (!w || !new_diag_r) return -1;
   try {
+    HIP_CHECK(hipSetDevice(w->device));
     w->ls.set_diag_r_host(new_diag_r);
     HIP_CHECK(hipStreamSynchronize(w->ls.stream));
   } catch (const std::exception &ex) {
@@ -859,7 +870,11 @@ scs_int scs_update_lin_sys_diag_r(ScsLinSysWork *w, const scs_float *new_diag_r)
   return 0;
 }
 
-void scs_free_lin_sys_work(ScsLinSysWork *w) { delete w; }
+void scs_free_lin_sys_work(ScsLinSysWork *w) {
+  if (!w) return;
+  (void)hipSetDevice(w->device);
+  delete w;
+}
 
 void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on) {
   if (w) w->ls.profiling = on != 0;
@@ -868,6 +883,7 @@ void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on) {
 void scs_amd_linsys_get_stats(const ScsLinSysWork *w, ScsAmdStats *out) {
   if (!w || !out) return;
   LinSys &ls = const_cast<LinSys &>(w->ls);
+  (void)hipSetDevice(w->device);
   (void)hipStreamSynchronize(ls.stream);
   ls.harvest_timers();
   memset(out, 0, sizeof *out);
