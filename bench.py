@@ -1,27 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- ADMM iterations/sec of the MI355X-native SCS hot path.
 
-Metric (BASELINE.json): "ADMM iters/sec + time-to-eps=1e-4, 1e6-var random SOCP,
-1 GPU".  Workload at N=1: BASELINE configs[1] -- random SOCP n=1e6, m=2e6,
-nnz=1e7 (col_nnz=10), zero + nonnegative + second-order cones, fp64, indirect
-(PCG) linear solves, default SCS settings except acceleration_lookback=0 (on this
-problem family the reference's own safeguard rejects every Anderson step; the AA-on
-figures are in DESIGN.md section 7).
+Metric (BASELINE.json): "ADMM iters/sec + time-to-eps=1e-4, 1e6-var random SOCP, 1 GPU".
+Workload at N=1: BASELINE configs[1] -- random SOCP n=1e6, m=2e6, nnz=1e7 (col_nnz=10), zero +
+nonnegative + second-order cones, fp64, indirect (PCG) linear solves, default SCS settings except
+acceleration_lookback=0 (on this family the reference's own safeguard rejects every Anderson step;
+AA-on figures are in DESIGN.md).
 
-A "step" is ONE ADMM iteration (linear-system solve by PCG + cone projection +
-the vector glue) on inputs resident in HBM.  The run does W untimed warm-up
-iterations, then times EXACTLY K iterations between barrier+synchronize pairs,
-then (N=1) keeps iterating to eps=1e-4 to report time-to-eps.  With N>1 each rank
-solves its own independent problem of the same size (weak scaling; the path has
-no intra-solve collective -- RCCL only carries the batch descriptor and the
-result records).
+A "step" is ONE ADMM iteration (linear-system solve by PCG + cone projection + the vector glue) on
+inputs resident in HBM.  Each rank (one process per GPU) runs W untimed warm-up iterations, times
+EXACTLY K iterations between barrier+synchronize pairs (`ms_per_step`, `window_it_per_s`), then
+keeps iterating to eps.  `value` follows SURVEY.md 8(d): iterations of the whole solve / its
+wall time (sum over ranks / max over ranks) -- it does not depend on which window --steps/--warmup
+select.  With N>1 every rank solves its own independent problem of the same size (weak scaling;
+the path has no intra-solve collective -- RCCL only carries the batch descriptor, the rank census
+and the result records) and then the batch workload of BASELINE configs[3] (8 problems of n=2e5
+per GPU, 4 host threads per GPU).
 
-One JSON line on stdout (rank 0).
+`python bench.py --gpus N` without a torchrun environment re-executes itself under
+torch.distributed.run with N ranks.  One JSON line on stdout (rank 0).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet (fp64 matrix = fp64 vector); the guide lists no fp64 figure
 
 
 def parse():
@@ -45,249 +50,523 @@ def parse():
     ap.add_argument("--aa", type=int, default=0, help="acceleration_lookback (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-eps", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2..4] side measurements")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not sample SpMV launches with HIP events in the timed region (roofline left empty)")
     ap.add_argument("--q-fixed", type=int, default=0,
                     help="many-small-cones variant of the same workload: every SOC has this size (SURVEY 8d)")
-    ap.add_argument("--cpu-sample-n", type=int, default=30000)
-    ap.add_argument("--cpu-omp-sample-n", type=int, default=30000,
-                    help="sample size for the OpenMP flavour of the reference (0 = skip it)")
-    ap.add_argument("--cpu-omp-threads", type=int, default=0, help="default min(nproc, 16)")
-    ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0,
-                    help="hard wall-clock cap (s) for each CPU baseline sample; it runs in a child process")
-    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-sample-i0", type=int, default=20)
-    ap.add_argument("--cpu-sample-iters", type=int, default=25)
+    ap.add_argument("--cpu-window-i0", type=int, default=1, help="CPU baseline: first ADMM iteration of the window")
+    ap.add_argument("--cpu-window-iters", type=int, default=2, help="CPU baseline: iterations in the window")
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=200.0,
+                    help="hard wall-clock cap (s) for each CPU baseline leg; each runs in a child process")
+    ap.add_argument("--cpu-omp-threads", type=int, default=0, help="OpenMP flavour: default nproc")
+    ap.add_argument("--cpu-sample-n", type=int, default=30000, help="fallback sample when the real-size leg times out")
+    ap.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--max-iters", type=int, default=20000)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f32 = the -DSFLOAT library (BASELINE configs[4]; residual tolerance relaxed to 1e-3)")
     ap.add_argument("--eps", type=float, default=0.0, help="eps_abs = eps_rel (default 1e-4; 1e-3 with --dtype f32)")
+    ap.add_argument("--batch-n", type=int, default=200000)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--batch-concurrency", type=int, default=4)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: launch-path self test on CPU
+    ap.add_argument("--stub-solver", action="store_true", help=argparse.SUPPRESS)  # no GPU: fake solver, same scaffolding
     return ap.parse_args()
 
 
-def cpu_baseline(args, full_n, threads=1):
-    """The reference's own CPU indirect solver (oracle/_ref, built from /root/reference by
-    oracle/Makefile) on the host cores, bounded sample: the same generator at a reduced n,
-    iterations [i0, i1) isolated by differencing two capped runs (the first iterations solve
-    to 1e-12 and are not representative), scaled linearly in nnz to the full size.
-    threads == 1: the stock build; threads > 1: the reference's USE_OPENMP flavour."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's own linsys/cpu/indirect (oracle/_ref, built from /root/reference by
+# oracle/Makefile), on the host cores, in child processes with hard timeouts.
+# ---------------------------------------------------------------------------------------------------
+def _cpu_worker(spec):
+    """child process: CPU only.  spec = kind:threads:n:col_nnz:seed:aa:q_fixed:i0:k"""
+    kind, threads, n, col_nnz, seed, aa, q_fixed, i0, k = spec.split(":")
+    threads, n, col_nnz, seed, aa, q_fixed, i0, k = map(int, (threads, n, col_nnz, seed, aa, q_fixed, i0, k))
     flavour = "libscsindir_ref.so" if threads == 1 else "libscsindir_ref_omp.so"
-    try:
-        from oracle import pyoracle
-        from scs_amd import capi, problems
-        if not pyoracle.ref_available():
-            return None
-        if threads > 1:
-            os.environ["OMP_NUM_THREADS"] = str(threads)  # read when libgomp initialises (first load)
-            # libgomp's default active spinning makes the reference's many tiny parallel regions
-            # 20x slower than serial whenever anything else shares the cores; passive waiting is its best case
-            os.environ["OMP_WAIT_POLICY"] = "passive"
-        ref = pyoracle.load_ref(flavour)
-        n = min(args.cpu_sample_n if threads == 1 else args.cpu_omp_sample_n, full_n)
-        pr = problems.random_socp(n, 2 * n, args.col_nnz, seed=args.seed, q_fixed=args.q_fixed or None)
+    if threads > 1:
+        os.environ["OMP_NUM_THREADS"] = str(threads)  # read when libgomp initialises (first load)
+        os.environ["OMP_WAIT_POLICY"] = "passive"     # active spinning makes the many tiny regions far slower
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    from oracle import pyoracle
+    from scs_amd import capi, problems
+    ref = pyoracle.load_ref(flavour)
+    t0 = time.time()
+    if kind == "sdp":  # configs[2]: per-projection cost of the reference's LAPACK dsyevr path
+        pr = problems.random_sdp(2000, 200, 50, 1001, 10, seed=1234)
         prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
-        i0, i1 = args.cpu_sample_i0, args.cpu_sample_i0 + args.cpu_sample_iters
-        t0 = time.time()
-        ra = capi.solve(ref, prob, verbose=0, acceleration_lookback=args.aa, max_iters=i0)["info"]
-        rb = capi.solve(ref, prob, verbose=0, acceleration_lookback=args.aa, max_iters=i1)["info"]
-        wall = time.time() - t0
-        dt = (rb["solve_time"] - ra["solve_time"]) / 1e3
-        its_per_s = (rb["iter"] - ra["iter"]) / dt
-        scale = n / float(full_n)
-        return dict(value=its_per_s * scale, unit="ADMM iters/sec", cores=threads, kind="reference",
-                    sample=(f"reference {flavour} (linsys/cpu/indirect, {threads} thread(s)) on the same generator at "
-                            f"n={n}, m={2*n}, nnz={n*args.col_nnz}: ADMM iterations {ra['iter']}..{rb['iter']} in "
-                            f"{dt:.2f} s = {its_per_s:.3f} it/s (difference of two capped runs), scaled by "
-                            f"n_sample/n_full={scale:g} (cost per iteration is linear in nnz)"),
-                    measured_it_per_s=its_per_s, sample_wall_s=wall, host_cores=os.cpu_count())
-    except Exception as e:  # the baseline is reported, never required
-        return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference", sample=f"unavailable: {e}")
+        r = capi.solve(ref, prob, verbose=0, acceleration_lookback=0, max_iters=k)["info"]
+        print(json.dumps(dict(cone_ms_per_projection=r["cone_time"] / max(r["iter"], 1), iters=r["iter"],
+                              wall_s=time.time() - t0)), flush=True)
+        return
+    pr = problems.random_socp(n, 2 * n, col_nnz, seed=seed, q_fixed=q_fixed or None)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    ra = capi.solve(ref, prob, verbose=0, acceleration_lookback=aa, max_iters=i0)["info"]
+    rb = capi.solve(ref, prob, verbose=0, acceleration_lookback=aa, max_iters=i0 + k)["info"]
+    dt = (rb["solve_time"] - ra["solve_time"]) / 1e3
+    print(json.dumps(dict(its_per_s=(rb["iter"] - ra["iter"]) / dt, window=[ra["iter"], rb["iter"]], window_s=dt,
+                          lin_sys_s=(rb["lin_sys_time"] - ra["lin_sys_time"]) / 1e3, flavour=flavour, threads=threads,
+                          n=n, wall_s=time.time() - t0)), flush=True)
 
 
-def cpu_baseline_bounded(args, full_n, threads):
-    """cpu_baseline() in a child process with a hard timeout, so that a slow or oversubscribed
-    host can never stall the bench line (the baseline is reported, never required)."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), "--n", str(full_n),
-           "--col-nnz", str(args.col_nnz), "--seed", str(args.seed), "--aa", str(args.aa),
-           "--q-fixed", str(args.q_fixed), "--cpu-sample-n", str(args.cpu_sample_n),
-           "--cpu-omp-sample-n", str(args.cpu_omp_sample_n), "--cpu-sample-i0", str(args.cpu_sample_i0),
-           "--cpu-sample-iters", str(args.cpu_sample_iters)]
+def _cpu_child(spec, timeout):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", spec]
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
-                           timeout=args.cpu_baseline_timeout)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
         return json.loads(p.stdout.strip().splitlines()[-1])
     except subprocess.TimeoutExpired:
-        return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference",
-                    sample=f"unavailable: sample exceeded the {args.cpu_baseline_timeout:.0f} s cap on this host")
+        return dict(error=f"exceeded the {timeout:.0f} s cap on this host")
+    except Exception as e:  # the baseline is reported, never required
+        return dict(error=str(e))
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(args, n, threads, gpu_window_its_per_s, gpu_cg_per_it_window, gpu_total_cg_its, gpu_iters_to_eps):
+    """The reference on the metric's own configuration (n as benchmarked): ADMM iterations [i0, i0+k)
+    isolated by differencing two capped runs (the part before i0 holds the 1e-12 solve for g), beside
+    the GPU's rate over the SAME iteration window.  Falls back to a small extrapolated sample if the
+    real-size leg does not finish inside the cap."""
+    i0, k = args.cpu_window_i0, args.cpu_window_iters
+    spec = f"socp:{threads}:{n}:{args.col_nnz}:{args.seed}:{args.aa}:{args.q_fixed}:{i0}:{k}"
+    r = _cpu_child(spec, args.cpu_baseline_timeout)
+    host = dict(host_cores=os.cpu_count(), cpu_model=_cpu_model())
+    if "its_per_s" in r:
+        out = dict(value=r["its_per_s"], unit="ADMM iters/sec", cores=threads, kind="reference",
+                   sample=(f"reference {r['flavour']} (linsys/cpu/indirect, {threads} thread(s)) on the SAME generator and "
+                           f"size (n={n}, m={2*n}, nnz={n*args.col_nnz}): ADMM iterations {r['window'][0]}..{r['window'][1]} "
+                           f"in {r['window_s']:.1f} s (difference of two capped runs, {r['wall_s']:.0f} s of CPU wall incl. setup)"),
+                   gpu_same_window_its_per_s=gpu_window_its_per_s, **host)
+        if gpu_window_its_per_s:
+            out["gpu_over_cpu_same_window"] = gpu_window_its_per_s / r["its_per_s"]
+        if gpu_cg_per_it_window and gpu_total_cg_its and gpu_iters_to_eps:
+            # CG iterations per ADMM iteration fall as the solve proceeds, so scale by CG work, not by iterations
+            cpu_s_per_cg = 1.0 / (r["its_per_s"] * gpu_cg_per_it_window)
+            out["cpu_time_to_eps_s_estimate"] = cpu_s_per_cg * gpu_total_cg_its
+            out["estimate_note"] = ("cpu seconds per CG iteration in the window x the CG iterations the GPU solve needed to reach eps "
+                                    f"({gpu_total_cg_its} over {gpu_iters_to_eps} ADMM iterations; same algorithm and tolerance schedule)")
+        return out
+    # fallback: cache-resident sample, extrapolated linearly in nnz (labelled as such)
+    ns = min(args.cpu_sample_n, n)
+    r2 = _cpu_child(f"socp:{threads}:{ns}:{args.col_nnz}:{args.seed}:{args.aa}:{args.q_fixed}:20:25", args.cpu_baseline_timeout)
+    if "its_per_s" in r2:
+        return dict(value=r2["its_per_s"] * ns / float(n), unit="ADMM iters/sec", cores=threads, kind="reference",
+                    sample=(f"EXTRAPOLATED: real-size leg {r.get('error')}; reference {r2['flavour']} at n={ns}: iterations "
+                            f"{r2['window'][0]}..{r2['window'][1]} = {r2['its_per_s']:.3f} it/s, scaled by {ns}/{n}"), **host)
+    return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference",
+                sample=f"unavailable: {r.get('error')} / {r2.get('error')}", **host)
+
+
+# ---------------------------------------------------------------------------------------------------
+# solver handles: the real one drives the C ABI; the stub exists so the launch / collect scaffolding
+# (self-spawn, rendezvous, barriers, reductions, JSON) can run as a 2-process gloo test without a GPU
+# ---------------------------------------------------------------------------------------------------
+class HipSolver:
+    def __init__(self, args, rank, local_rank, n, m, col_nnz, seed, aa, eps, dtype="f64", q_fixed=0):
+        from scs_amd import capi, problems
+        self.capi = capi
+        self.lib = capi.load("libscsamd_f32.so" if dtype == "f32" else "libscsamd.so")
+        self.T = T = self.lib._scs_types
+        assert self.lib.scs_amd_set_device(local_rank) == 0
+        t0 = time.time()
+        pr = problems.random_socp(n, m, col_nnz, seed=seed + rank, dtype=T.np_float, q_fixed=q_fixed or None)
+        self.cone = pr["cone"]
+        self.prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
+        self.t_gen = time.time() - t0
+        st = capi.default_settings(self.lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters, eps_abs=eps,
+                                   eps_rel=eps)
+        t0 = time.time()
+        self.w = self.lib.scs_init(C.byref(self.prob.data), C.byref(self.prob.k), C.byref(st))
+        if not self.w:
+            raise SystemExit("scs_init failed")
+        self.t_init = time.time() - t0
+        self.x = np.zeros(n, dtype=T.np_float)
+        self.y = np.zeros(m, dtype=T.np_float)
+        self.s = np.zeros(m, dtype=T.np_float)
+        self.sol = T.ScsSolution(self.x.ctypes.data_as(T.fp), self.y.ctypes.data_as(T.fp), self.s.ctypes.data_as(T.fp))
+        self.info = T.ScsInfo()
+        self.max_iters = args.max_iters
+
+    def begin(self):
+        assert self.lib.scs_amd_solve_begin(self.w, None, 0) == 0
+
+    def steps(self, k):
+        it = self.lib.scs_amd_solve_steps(self.w, k)
+        assert it >= 0
+        return it
+
+    def converged(self):
+        return bool(self.lib.scs_amd_solve_converged(self.w))
+
+    def stats(self):
+        s = self.T.ScsAmdStats()
+        self.lib.scs_amd_get_stats(self.w, C.byref(s))
+        return {k: getattr(s, k) for k, _ in self.T.ScsAmdStats._fields_}
+
+    def profiling(self, on):
+        self.lib.scs_amd_set_profiling(self.w, 1 if on else 0)
+
+    def end(self):
+        self.lib.scs_amd_solve_end(self.w, C.byref(self.sol), C.byref(self.info))
+        return self.capi.info_dict(self.info)
+
+    def close(self):
+        self.lib.scs_finish(self.w)
+
+
+class StubSolver:
+    """launch-path self test only (--stub-solver): pretends every iteration takes 2 ms"""
+    t_gen = t_init = 0.0
+    cone = dict(z=0, l=0, q=[])
+
+    def __init__(self, rank):
+        self.it, self.rank, self.max_iters = 0, rank, 10 ** 9
+
+    def begin(self):
+        self.it = 0
+
+    def steps(self, k):
+        for _ in range(k):
+            if self.converged():
+                break
+            time.sleep(0.002)
+            self.it += 1
+        return self.it
+
+    def converged(self):
+        return self.it >= 25 * (2 + self.rank)
+
+    def stats(self):
+        return dict(cg_iters=10 * self.it, spmv_launches=0, spmv_ms=0.0, spmv_bytes=0, cone_ms=0.0, cone_projs=0)
+
+    def profiling(self, on):
+        pass
+
+    def end(self):
+        return dict(status_val=1, status="solved", iter=self.it, pobj=0.0, dobj=0.0, res_pri=0.0, res_dual=0.0, gap=0.0,
+                    solve_time=2.0 * self.it)
+
+    def close(self):
+        pass
+
+
+def respawn(args):
+    """`python bench.py --gpus N` outside torchrun: become N ranks (one process per GPU) of ONE node."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ---------------------------------------------------------------------------------------------------
+def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev):
+    """BASELINE configs[3]: independent n=2e5 SOCPs, `batch_per_gpu` per GPU (problem j -> rank j % world),
+    `batch_concurrency` host threads per GPU each driving its own ScsWork / HIP stream; RCCL carries the
+    descriptor (broadcast) and the result records (all-gather): scs_amd/batch.py."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scs_amd import batch, capi, problems
+    lib = capi.load(lib_name)
+    count = args.batch_per_gpu * world
+    desc = batch.broadcast_descriptor(dict(n=args.batch_n, m=2 * args.batch_n, col_nnz=args.col_nnz, seed=1000, count=count,
+                                           aa=0, max_iters=args.max_iters), dist, dev)
+    mine = batch.partition(desc["count"], world, rank)
+    probs = {}
+    for j in mine:  # generation is not part of the timed region
+        pr = problems.random_socp(desc["n"], desc["m"], desc["col_nnz"], seed=desc["seed"] + j)
+        probs[j] = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+
+    def solve_one(j):
+        lib.scs_amd_set_device(local_rank)
+        i = capi.solve(lib, probs[j], verbose=0, acceleration_lookback=0, max_iters=desc["max_iters"])["info"]
+        return (j, i["status_val"], i["iter"], i["pobj"], i["dobj"], i["res_pri"], i["res_dual"], i["gap"],
+                i["solve_time"] + i["setup_time"])
+
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, args.batch_concurrency)) as ex:
+        recs = list(ex.map(solve_one, mine))
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    tab = batch.gather_records(recs, desc["count"], dist, dev)
+    wall = float(el.item())
+    return dict(workload=f"BASELINE configs[3]: {count} independent random SOCPs n={desc['n']} m={desc['m']}, {args.batch_per_gpu} per GPU, "
+                         f"{args.batch_concurrency} host threads per GPU, setup (scs_init) inside the timed region",
+                problems=count, wall_s=wall, problems_per_s=count / wall, admm_iters_per_s=float(np.nansum(tab[:, 2])) / wall,
+                all_solved=bool(np.all(tab[:, 1] == 1)), iters_min_max=[int(np.nanmin(tab[:, 2])), int(np.nanmax(tab[:, 2]))])
+
+
+def secondary_single_gpu(args):
+    """Driver-timed side measurements on rank 0 at N=1: BASELINE configs[2] (SDP), configs[4] (fp32)."""
+    import torch
+    from scs_amd import capi, problems
+    out = {}
+    # ---- configs[2]: 200 PSD blocks of 50x50 + box(1001): wall time per cone projection, flop rate vs the fp64 matrix peak
+    try:
+        lib = capi.load("libscsamd.so")
+        pr = problems.random_sdp(2000, 200, 50, 1001, 10, seed=1234)
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+        t0 = time.time()
+        r = capi.solve(lib, prob, verbose=0, acceleration_lookback=0, want_stats=True, profiling=True)
+        wall = time.time() - t0
+        st = r["stats"]
+        ms_proj = st["cone_ms"] / max(st["cone_projs"], 1)
+        flop = 200 * 10.0 * 50 ** 3  # SURVEY 8d: ~10 k^3 per block
+        d = dict(workload="BASELINE configs[2]: random SDP n=2000, 200 PSD blocks 50x50 + box(1001)", status=r["info"]["status"],
+                 iters=r["info"]["iter"], solve_s=r["info"]["solve_time"] / 1e3, wall_s=wall,
+                 ms_per_projection=ms_proj, projections_timed=st["cone_projs"], flop_per_projection_model=flop,
+                 achieved_tflops=flop / (ms_proj * 1e-3) / 1e12 if ms_proj > 0 else None,
+                 fp64_matrix_peak_tflops=FP64_MATRIX_PEAK_TFLOPS, psd_unconverged=st.get("psd_unconverged"))
+        if d["achieved_tflops"]:
+            d["mfma_frac"] = d["achieved_tflops"] / FP64_MATRIX_PEAK_TFLOPS
+        d["note"] = ("10 k^3-flop model of the dense eigensolve; only the similarity transform and the reconstruction run on the "
+                     "fp64 matrix cores, the Jacobi sweeps are VALU/LDS work (DESIGN.md)")
+        if not args.no_cpu_baseline:
+            c = _cpu_child("sdp:1:0:0:0:0:0:0:40", args.cpu_baseline_timeout)
+            d["cpu_reference_ms_per_projection"] = c.get("cone_ms_per_projection", None)
+            d["cpu_reference_note"] = ("reference src/cones.c:999-1067 (LAPACK dsyevr via scipy's OpenBLAS, 1 thread), 40 iterations"
+                                       if "cone_ms_per_projection" in c else f"unavailable: {c.get('error')}")
+        out["configs2_sdp"] = d
     except Exception as e:
-        return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference", sample=f"unavailable: {e}")
+        out["configs2_sdp"] = dict(error=str(e))
+    # ---- configs[4]: fp32 n=4e6, windowed rate + SpMV bandwidth
+    try:
+        s = HipSolver(args, 0, 0, 4000000, 8000000, args.col_nnz, args.seed, 0, 1e-3, dtype="f32")
+        s.begin()
+        s.steps(10)
+        st0 = s.stats()
+        s.profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.steps(20)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st1 = s.stats()
+        s.profiling(False)
+        s.end()
+        nl, ms = st1["spmv_launches"] - st0["spmv_launches"], st1["spmv_ms"] - st0["spmv_ms"]
+        d = dict(workload="BASELINE configs[4]: SFLOAT random SOCP n=4e6 m=8e6 nnz=4e7, iterations 10..30", dtype="f32",
+                 window_it_per_s=20 / el, ms_per_step=1e3 * el / 20, cg_its_per_admm_iter=(st1["cg_iters"] - st0["cg_iters"]) / 20.0,
+                 setup_s=dict(generate=s.t_gen, scs_init=s.t_init))
+        if nl > 0 and ms > 0:
+            bps = st1["spmv_bytes"] / 2.0
+            d["spmv_avg_launch_us"] = 1e3 * ms / nl
+            d["spmv_gbs"] = bps / (ms / nl * 1e-3) / 1e9
+            d["spmv_frac_of_8TBs"] = d["spmv_gbs"] / HBM_PEAK_GBS
+        s.close()
+        out["configs4_fp32"] = d
+    except Exception as e:
+        out["configs4_fp32"] = dict(error=str(e))
+    return out
 
 
 def main():
     args = parse()
-    if args.cpu_baseline_worker:  # child of cpu_baseline_bounded: CPU only, no GPU, no torch
-        print(json.dumps(cpu_baseline(args, args.n, threads=args.cpu_baseline_worker)), flush=True)
+    if args.cpu_baseline_worker:  # child process: CPU only, no GPU, no torch
+        _cpu_worker(args.cpu_baseline_worker)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        respawn(args)
     n = args.n
     m = args.m or 2 * n
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
+    stub = args.stub_solver
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+    dev = "cpu" if stub else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group(backend="nccl")  # RCCL
-    from scs_amd import capi, problems
-    lib = capi.load("libscsamd_f32.so" if args.dtype == "f32" else "libscsamd.so")
-    T = lib._scs_types
-    assert lib.scs_amd_set_device(local_rank) == 0
+        dist.init_process_group(backend=args.backend)  # "nccl" IS RCCL on ROCm
     eps = args.eps or (1e-3 if args.dtype == "f32" else 1e-4)
-
-    # ---- batch descriptor: rank 0 decides, RCCL broadcast (launch) -------------
-    desc = torch.tensor([n, m, args.col_nnz, args.seed, args.steps, args.warmup, args.aa], dtype=torch.int64,
-                        device="cuda")
-    if dist:
-        dist.broadcast(desc, src=0)
-    n, m, col_nnz, seed, K, W, aa = [int(v) for v in desc.tolist()]
-
-    # ---- synthetic problem, one per rank (seed + rank) --------------------------
-    t0 = time.time()
-    pr = problems.random_socp(n, m, col_nnz, seed=seed + rank, dtype=T.np_float, q_fixed=args.q_fixed or None)
-    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
-    t_gen = time.time() - t0
-    st = capi.default_settings(lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters, eps_abs=eps,
-                               eps_rel=eps)
-    t0 = time.time()
-    w = lib.scs_init(C.byref(prob.data), C.byref(prob.k), C.byref(st))
-    if not w:
-        raise SystemExit("scs_init failed")
-    t_init = time.time() - t0
-    x = np.zeros(n, dtype=T.np_float); y = np.zeros(m, dtype=T.np_float); s = np.zeros(m, dtype=T.np_float)
-    sol = T.ScsSolution(x.ctypes.data_as(T.fp), y.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp))
-    info = T.ScsInfo()
 
     def barrier():
         if dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
-    # ---- warm-up: everything scs_solve does before the loop + W iterations -----
-    t_solve0 = time.time()
-    assert lib.scs_amd_solve_begin(w, None, 0) == 0
-    it = lib.scs_amd_solve_steps(w, W)
-    assert it >= 0
-    stats0 = T.ScsAmdStats()
-    lib.scs_amd_get_stats(w, C.byref(stats0))
+    # ---- rank census over the collective backend: proves N ranks took part ------------------------
+    me = torch.tensor([rank], dtype=torch.int64, device=dev)
+    seen = [me]
+    if dist:
+        seen = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(seen, me)
+    ranks_seen = sorted(int(t.item()) for t in seen)
+
+    # ---- batch descriptor: rank 0 decides, broadcast (launch) --------------------------------------
+    desc = torch.tensor([n, m, args.col_nnz, args.seed, args.steps, args.warmup, args.aa], dtype=torch.int64, device=dev)
+    if dist:
+        dist.broadcast(desc, src=0)
+    n, m, col_nnz, seed, K, W, aa = [int(v) for v in desc.tolist()]
+
+    # ---- synthetic problem, one per rank (seed + rank) ----------------------------------------------
+    S = StubSolver(rank) if stub else HipSolver(args, rank, local_rank, n, m, col_nnz, seed, aa, eps, args.dtype, args.q_fixed)
+    cone = S.cone
+    setup_s = {"generate": S.t_gen, "scs_init": S.t_init}
+
+    # ---- the solve: warm-up W, timed window of K, then on to eps -----------------------------------
+    barrier()
+    t_solve0 = time.perf_counter()
+    S.begin()
+    it = S.steps(W)
+    stats0 = S.stats()
     if not args.no_kernel_timing:
-        lib.scs_amd_set_profiling(w, 1)  # samples 1 in 8 SpMV launches with HIP events on OUR stream
-    # ---- timed region: exactly K ADMM iterations --------------------------------
+        S.profiling(True)  # samples 1 in 8 SpMV launches with HIP events on OUR stream
     barrier()
     t0 = time.perf_counter()
-    it2 = lib.scs_amd_solve_steps(w, K)
+    it2 = S.steps(K)
     barrier()
     elapsed = time.perf_counter() - t0
-    assert it2 >= 0
     steps_done = it2 - it
-    stats1 = T.ScsAmdStats()
-    lib.scs_amd_get_stats(w, C.byref(stats1))
-    lib.scs_amd_set_profiling(w, 0)
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    steps_t = torch.tensor([steps_done], dtype=torch.int64, device="cuda")
-    if dist:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(steps_t, op=dist.ReduceOp.SUM)
-    elapsed_max = float(t_max.item())
-    total_steps = int(steps_t.item())
-
-    # ---- run on to eps = 1e-4 (time-to-eps), N = 1 only in the JSON -------------
-    tte = None
+    stats1 = S.stats()
+    S.profiling(False)
     if not args.no_time_to_eps:
-        while not lib.scs_amd_solve_converged(w):
-            cur = lib.scs_amd_solve_steps(w, 100)
-            if cur < 0 or cur >= args.max_iters:
+        while not S.converged():
+            if S.steps(100) >= S.max_iters:
                 break
+    if not stub:
         torch.cuda.synchronize()
-        tte = time.time() - t_solve0
-    lib.scs_amd_solve_end(w, C.byref(sol), C.byref(info))
-    res = capi.info_dict(info)
+    solve_wall = time.perf_counter() - t_solve0  # includes the two window barriers (microseconds)
+    stats2 = S.stats()
+    res = S.end()
 
-    # ---- result records gathered over RCCL (collect) -----------------------------
+    red = torch.tensor([elapsed, solve_wall], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([steps_done, res["iter"]], dtype=torch.int64, device=dev)
+    if dist:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed_max, solve_wall_max = [float(v) for v in red.tolist()]
+    total_steps, total_iters = [int(v) for v in cnt.tolist()]
+
+    # ---- result records gathered over the collective backend (collect) ----------------------------
     rec = torch.tensor([res["status_val"], res["iter"], res["pobj"], res["dobj"], res["res_pri"], res["res_dual"],
-                        res["gap"], res["solve_time"]], dtype=torch.float64, device="cuda")
+                        res["gap"], res["solve_time"]], dtype=torch.float64, device=dev)
     recs = [rec]
     if dist:
         recs = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(recs, rec)
 
+    # ---- GPU rate over the CPU baseline's iteration window (rank 0, N = 1) -------------------------
+    gpu_win = gpu_cg_win = None
+    want_cpu = world == 1 and not args.no_cpu_baseline and args.dtype == "f64" and not stub
+    if want_cpu:
+        S.begin()
+        S.steps(args.cpu_window_i0)
+        sa = S.stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S.steps(args.cpu_window_iters)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sb = S.stats()
+        S.end()
+        gpu_win = args.cpu_window_iters / dt
+        gpu_cg_win = (sb["cg_iters"] - sa["cg_iters"]) / float(args.cpu_window_iters)
+    S.close()  # free the headline problem before the side workloads
+
+    batch_out = None
+    if not stub and not args.no_secondary and args.dtype == "f64":
+        try:
+            batch_out = batch_workload(args, "libscsamd.so", rank, world, local_rank, dist, torch, dev)
+        except Exception as e:
+            batch_out = dict(error=str(e))
+
     if rank == 0:
-        cg_its = stats1.cg_iters - stats0.cg_iters
-        spmv_samples = stats1.spmv_launches - stats0.spmv_launches
-        spmv_ms = stats1.spmv_ms - stats0.spmv_ms
-        bytes_per_spmv = stats1.spmv_bytes / 2.0  # already computed with sizeof(scs_float) of the library
+        cg_its = stats1["cg_iters"] - stats0["cg_iters"]
+        spmv_samples = stats1["spmv_launches"] - stats0["spmv_launches"]
+        spmv_ms = stats1["spmv_ms"] - stats0["spmv_ms"]
+        bytes_per_spmv = stats1["spmv_bytes"] / 2.0  # already computed with sizeof(scs_float) of the library
         roof = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
                     kernel="csr_wave_kernel (wave-owned rows CSR SpMV, both orientations)")
         if spmv_samples > 0 and spmv_ms > 0:
             avg_s = spmv_ms / spmv_samples * 1e-3
             roof["achieved"] = bytes_per_spmv / avg_s / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-            # context only: the best pure streaming kernel measured on this chip (lab/spmv_lab.hip) reaches 6.9 TB/s
-            roof["frac_of_measured_stream_6900GBs"] = roof["achieved"] / 6900.0
             roof["avg_launch_us"] = avg_s * 1e6
             roof["algorithmic_bytes_per_launch"] = bytes_per_spmv
             roof["launches_timed"] = int(spmv_samples)
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this
-        # process); only quoted for the exact workload it was measured on
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
+        # only quoted for the exact workload it was measured on
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if n == 1000000 and m == 2000000 and col_nnz == 10:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+            if n == 1000000 and m == 2000000 and col_nnz == 10 and not stub:
                 roof["traffic"] = pj["hbm_bytes_per_launch_mean"]
-                roof["traffic_source"] = "profiles/r1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+                roof["traffic_source"] = pj.get("source", "profiles/r2_pmc_traffic.json")
         except Exception:
             pass
         out = {
-            "metric": "ADMM iters/sec (+ time-to-eps=1e-4), 1e6-var random SOCP, 1 GPU",
-            "value": total_steps / elapsed_max,
+            "metric": "ADMM iters/sec (+ time-to-eps=1e-4), 1e6-var random SOCP, 1 GPU" if not stub else "stub (launch-path self test)",
+            "value": total_iters / solve_wall_max,
+            "value_definition": "ADMM iterations of the whole solve to eps (sum over ranks) / wall time of that solve (max over "
+                                "ranks): SURVEY 8(d) info.iter / solve_time",
             "unit": "ADMM iters/sec",
             "n_gpus": world,
+            "rccl_ranks_seen": ranks_seen,
             "steps": K,
             "warmup": W,
             "ms_per_step": 1e3 * elapsed_max / max(steps_done, 1),
+            "window_it_per_s": total_steps / elapsed_max,
+            "us_per_cg_iter": 1e6 * elapsed / cg_its if cg_its else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic",
+            "data": "synthetic" if not stub else "stub",
             "config": {"workload": f"random SOCP n={n} m={m} nnz={n*col_nnz} (BASELINE configs[1]"
                                    f"{', many-small-cones variant q_i=%d' % args.q_fixed if args.q_fixed else ''}); "
-                                   f"cones z={pr['cone']['z']} l={pr['cone']['l']} soc={len(pr['cone']['q'])}; "
+                                   f"cones z={cone['z']} l={cone['l']} soc={len(cone['q'])}; "
                                    f"indirect PCG; acceleration_lookback={aa}",
                        "n": n, "m": m, "nnz": n * col_nnz, "problems_per_gpu": 1,
-                       "partition": "one independent problem per GPU"},
+                       "partition": "one independent problem per GPU (seed + rank)"},
             "roofline": roof,
             "cg_its_per_admm_iter": cg_its / max(steps_done, 1),
-            "time_to_eps_s": tte,
+            "cg_its_total": stats2["cg_iters"],
+            "time_to_eps_s": None if args.no_time_to_eps else solve_wall_max,
+            "info_solve_time_s_rank0": res["solve_time"] / 1e3,
             "iters_to_eps": res["iter"] if res["status_val"] == 1 else None,
             "status": res["status"],
             "final": {k: res[k] for k in ("pobj", "dobj", "res_pri", "res_dual", "gap", "iter")},
-            "setup_s": {"generate": t_gen, "scs_init": t_init},
+            "setup_s": setup_s,
             "results_per_rank": [[float(v) for v in r.tolist()] for r in recs],
+            "eps": eps,
         }
-        out["eps"] = eps
-        if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
-            out["cpu_baseline"] = cpu_baseline_bounded(args, n, 1)
-            if args.cpu_omp_sample_n > 0:  # SURVEY 8d: also the reference's OpenMP flavour on the host cores
-                nthr = args.cpu_omp_threads or min(os.cpu_count() or 1, 16)
-                out["cpu_baseline_omp"] = cpu_baseline_bounded(args, n, max(2, nthr))
+        if batch_out is not None:
+            out["batch"] = batch_out
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, n, 1, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
+            nthr = args.cpu_omp_threads or (os.cpu_count() or 1)
+            out["cpu_baseline_omp"] = cpu_baseline(args, n, max(2, nthr), gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not stub and not args.no_secondary and args.dtype == "f64":
+            out["secondary"] = secondary_single_gpu(args)
         print(json.dumps(out), flush=True)
-    lib.scs_finish(w)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -101,8 +101,8 @@ def test_two_rank_gloo_batch_matches_serial():
 
 
 def test_bench_cpu_baseline_worker_runs_without_a_gpu():
-    """bench.py's cpu_baseline leg is a CPU-only child process (the reference build on the host
-    cores); it must work where there is no GPU and print one JSON object."""
+    """bench.py's cpu_baseline legs are CPU-only child processes (the reference build on the host
+    cores): they must work where there is no GPU and print one JSON object each."""
     import json
     import subprocess
     import sys
@@ -110,10 +110,31 @@ def test_bench_cpu_baseline_worker_runs_without_a_gpu():
     if not pyoracle.ref_available():
         pytest.skip("oracle/_ref not built")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-worker", "1", "--n", "100000",
-                          "--cpu-sample-n", "1500", "--cpu-sample-i0", "5", "--cpu-sample-iters", "10"],
+    # spec = kind:threads:n:col_nnz:seed:aa:q_fixed:i0:k
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-worker", "socp:1:1500:10:1234:0:0:5:10"],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
     d = json.loads(out.stdout.strip().splitlines()[-1])
-    assert d["kind"] == "reference" and d["cores"] == 1 and d["unit"] == "ADMM iters/sec"
-    assert d["value"] is not None and d["value"] > 0, d
-    assert "n=1500" in d["sample"]
+    assert d["threads"] == 1 and d["n"] == 1500 and d["window"] == [5, 15]
+    assert d["its_per_s"] > 0 and d["window_s"] > 0, d
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` outside torchrun re-executes itself as 2 ranks (the launch path the
+    driver's scaling run depends on): same rendezvous, barriers, reductions and JSON assembly as on
+    GPUs, over gloo with the stub solver (no GPU in this container)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-solver", "--backend", "gloo",
+                          "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                         timeout=300, env=env)
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == [0, 1]
+    assert d["steps"] == 3 and d["warmup"] == 1
+    assert len(d["results_per_rank"]) == 2
+    iters = [int(r[1]) for r in d["results_per_rank"]]
+    assert iters == [50, 75]  # the stub's ranks converge at different iterations
+    # value = all ranks' iterations / the slowest rank's wall time; the window figure is separate
+    assert d["value"] > 0 and d["window_it_per_s"] > 0 and abs(d["ms_per_step"] - 2.0) < 2.0
