@@ -100,23 +100,35 @@ def _cpu_worker(spec):
         return
     pr = problems.random_socp(n, 2 * n, col_nnz, seed=seed, q_fixed=q_fixed or None)
     prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
-    ra = capi.solve(ref, prob, verbose=0, acceleration_lookback=aa, max_iters=i0)["info"]
-    rb = capi.solve(ref, prob, verbose=0, acceleration_lookback=aa, max_iters=i0 + k)["info"]
-    dt = (rb["solve_time"] - ra["solve_time"]) / 1e3
-    print(json.dumps(dict(its_per_s=(rb["iter"] - ra["iter"]) / dt, window=[ra["iter"], rb["iter"]], window_s=dt,
-                          lin_sys_s=(rb["lin_sys_time"] - ra["lin_sys_time"]) / 1e3, flavour=flavour, threads=threads,
-                          n=n, wall_s=time.time() - t0)), flush=True)
+    r = capi.solve(ref, prob, verbose=0, acceleration_lookback=aa, max_iters=i0 + k)["info"]  # ONE capped run
+    print(json.dumps(dict(iter=r["iter"], solve_s=r["solve_time"] / 1e3, lin_sys_s=r["lin_sys_time"] / 1e3,
+                          setup_s=r["setup_time"] / 1e3, flavour=flavour, threads=threads, n=n, wall_s=time.time() - t0)), flush=True)
 
 
-def _cpu_child(spec, timeout):
+def _cpu_start(spec):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", spec]
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
-        return json.loads(p.stdout.strip().splitlines()[-1])
+        return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True), time.time()
+    except Exception as e:
+        return e, time.time()
+
+
+def _cpu_collect(handle, timeout):
+    p, t_start = handle
+    if isinstance(p, Exception):
+        return dict(error=str(p))
+    try:
+        out, _ = p.communicate(timeout=max(1.0, timeout - (time.time() - t_start)))
+        return json.loads(out.strip().splitlines()[-1])
     except subprocess.TimeoutExpired:
+        p.kill()  # our own child, by handle
         return dict(error=f"exceeded the {timeout:.0f} s cap on this host")
     except Exception as e:  # the baseline is reported, never required
         return dict(error=str(e))
+
+
+def _cpu_child(spec, timeout):
+    return _cpu_collect(_cpu_start(spec), timeout)
 
 
 def _cpu_model():
@@ -129,20 +141,45 @@ def _cpu_model():
     return None
 
 
-def cpu_baseline(args, n, threads, gpu_window_its_per_s, gpu_cg_per_it_window, gpu_total_cg_its, gpu_iters_to_eps):
+def cpu_spec(args, n, threads, iters):
+    return f"socp:{threads}:{n}:{args.col_nnz}:{args.seed}:{args.aa}:{args.q_fixed}:0:{iters}"
+
+
+def cpu_start_pair(args, n, threads, parallel):
+    """two capped runs (max_iters = i0 and i0 + k); side by side when `parallel` (the 1-thread flavour)"""
+    a = _cpu_start(cpu_spec(args, n, threads, args.cpu_window_i0))
+    if not parallel:
+        return [a, None]
+    return [a, _cpu_start(cpu_spec(args, n, threads, args.cpu_window_i0 + args.cpu_window_iters))]
+
+
+def cpu_collect_pair(args, n, threads, pair):
+    ra = _cpu_collect(pair[0], args.cpu_baseline_timeout)
+    if "error" in ra:
+        return ra
+    hb = pair[1] if pair[1] is not None else _cpu_start(cpu_spec(args, n, threads, args.cpu_window_i0 + args.cpu_window_iters))
+    rb = _cpu_collect(hb, args.cpu_baseline_timeout)
+    if "error" in rb:
+        return rb
+    dt = rb["solve_s"] - ra["solve_s"]
+    if dt <= 0 or rb["iter"] <= ra["iter"]:
+        return dict(error="capped runs did not separate")
+    return dict(its_per_s=(rb["iter"] - ra["iter"]) / dt, window=[ra["iter"], rb["iter"]], window_s=dt, flavour=rb["flavour"],
+                wall_s=max(ra["wall_s"], rb["wall_s"]) if pair[1] is not None else ra["wall_s"] + rb["wall_s"], setup_s=rb["setup_s"])
+
+
+def cpu_baseline(args, n, threads, pair, gpu_window_its_per_s, gpu_cg_per_it_window, gpu_total_cg_its, gpu_iters_to_eps):
     """The reference on the metric's own configuration (n as benchmarked): ADMM iterations [i0, i0+k)
-    isolated by differencing two capped runs (the part before i0 holds the 1e-12 solve for g), beside
-    the GPU's rate over the SAME iteration window.  Falls back to a small extrapolated sample if the
-    real-size leg does not finish inside the cap."""
-    i0, k = args.cpu_window_i0, args.cpu_window_iters
-    spec = f"socp:{threads}:{n}:{args.col_nnz}:{args.seed}:{args.aa}:{args.q_fixed}:{i0}:{k}"
-    r = _cpu_child(spec, args.cpu_baseline_timeout)
+    isolated by differencing two capped runs (iteration 0 solves its linear system to the 1e-12 floor and is
+    not representative), beside the GPU's rate over the SAME iteration window.  Falls back to a small
+    extrapolated sample if the real-size leg does not finish inside the cap."""
+    r = cpu_collect_pair(args, n, threads, pair)
     host = dict(host_cores=os.cpu_count(), cpu_model=_cpu_model())
     if "its_per_s" in r:
         out = dict(value=r["its_per_s"], unit="ADMM iters/sec", cores=threads, kind="reference",
                    sample=(f"reference {r['flavour']} (linsys/cpu/indirect, {threads} thread(s)) on the SAME generator and "
                            f"size (n={n}, m={2*n}, nnz={n*args.col_nnz}): ADMM iterations {r['window'][0]}..{r['window'][1]} "
-                           f"in {r['window_s']:.1f} s (difference of two capped runs, {r['wall_s']:.0f} s of CPU wall incl. setup)"),
+                           f"in {r['window_s']:.1f} s (difference of two capped runs' solve_time; {r['wall_s']:.0f} s of CPU wall incl. generation and scs_init)"),
                    gpu_same_window_its_per_s=gpu_window_its_per_s, **host)
         if gpu_window_its_per_s:
             out["gpu_over_cpu_same_window"] = gpu_window_its_per_s / r["its_per_s"]
@@ -155,7 +192,8 @@ def cpu_baseline(args, n, threads, gpu_window_its_per_s, gpu_cg_per_it_window, g
         return out
     # fallback: cache-resident sample, extrapolated linearly in nnz (labelled as such)
     ns = min(args.cpu_sample_n, n)
-    r2 = _cpu_child(f"socp:{threads}:{ns}:{args.col_nnz}:{args.seed}:{args.aa}:{args.q_fixed}:20:25", args.cpu_baseline_timeout)
+    a2 = argparse.Namespace(**dict(vars(args), cpu_window_i0=20, cpu_window_iters=25))
+    r2 = cpu_collect_pair(a2, ns, threads, cpu_start_pair(a2, ns, threads, threads == 1))
     if "its_per_s" in r2:
         return dict(value=r2["its_per_s"] * ns / float(n), unit="ADMM iters/sec", cores=threads, kind="reference",
                     sample=(f"EXTRAPOLATED: real-size leg {r.get('error')}; reference {r2['flavour']} at n={ns}: iterations "
@@ -384,6 +422,9 @@ def main():
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         respawn(args)
+    # the libraries print warnings with C stdio (like the reference does); keep fd 1 clean for the ONE JSON line
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     n = args.n
     m = args.m or 2 * n
     rank = int(os.environ.get("RANK", "0"))
@@ -489,6 +530,9 @@ def main():
         gpu_win = args.cpu_window_iters / dt
         gpu_cg_win = (sb["cg_iters"] - sa["cg_iters"]) / float(args.cpu_window_iters)
     S.close()  # free the headline problem before the side workloads
+    cpu1 = cpu_omp = None
+    if want_cpu and rank == 0:  # one core: runs beside the GPU side workloads; the OpenMP leg starts after them
+        cpu1 = cpu_start_pair(args, n, 1, True)
 
     batch_out = None
     if not stub and not args.no_secondary and args.dtype == "f64":
@@ -558,15 +602,16 @@ def main():
         }
         if batch_out is not None:
             out["batch"] = batch_out
-        if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, n, 1, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
-            nthr = args.cpu_omp_threads or (os.cpu_count() or 1)
-            out["cpu_baseline_omp"] = cpu_baseline(args, n, max(2, nthr), gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
-        else:
-            out["cpu_baseline"] = None
         if world == 1 and not stub and not args.no_secondary and args.dtype == "f64":
             out["secondary"] = secondary_single_gpu(args)
-        print(json.dumps(out), flush=True)
+        if want_cpu:
+            nthr = max(2, args.cpu_omp_threads or (os.cpu_count() or 1))
+            cpu_omp = cpu_start_pair(args, n, nthr, False)
+            out["cpu_baseline"] = cpu_baseline(args, n, 1, cpu1, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
+            out["cpu_baseline_omp"] = cpu_baseline(args, n, nthr, cpu_omp, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
+        else:
+            out["cpu_baseline"] = None
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

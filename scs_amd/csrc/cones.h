@@ -16,6 +16,8 @@ struct ConeDev {
   // box cone
   DevBuf<real> bl, bu;      // bsize-1 each (already D-normalised, +-inf applied)
   DevBuf<real> box_t;       // [0] Newton warm start (reference c->box_t_warm_start)
+  bool box_multi = false;   // large box: Newton steps as chip-wide launches (k_box_step), else one workgroup (k_box)
+  DevBuf<real> box_part, box_ctl;
   // second-order cones
   int n_tiny = 0;           // cones with q <= SOC_TINY_MAX: one lane per cone
   DevBuf<int> tiny_off, tiny_len;

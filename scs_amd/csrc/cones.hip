@@ -124,6 +124,98 @@ __global__ __launch_bounds__(BOX_THREADS) void k_box(real *tx, const real *__res
 }
 
 // ----------------------------------------------------------------------------
+// box cone, large bsize: the same Newton iteration spread over the chip.  One launch per Newton step
+// (k_box_step) in the device-controlled pattern of the PCG: step `it` first finishes step it-1 -- every
+// workgroup re-reduces the previous step's per-workgroup partials of (g, h) in the same fixed order, so all
+// of them hold the same new t; workgroup 0 publishes it -- and, unless the stop tests of
+// src/cones.c:1231-1232 fired, forms its slice's partials at the new t.  Steps enqueued past convergence
+// return at once.  k_box_apply clamps x with the final t.  A 1e6-row box costs ~4 passes over 24 MB on the
+// whole chip instead of 25 on one CU.
+// ----------------------------------------------------------------------------
+struct BoxCtl {
+  real t[2];  // Newton iterate published by step it, slot it & 1
+  real t_cur; // latest published iterate (what k_box_apply uses)
+  int done;
+};
+constexpr int BOX_MULTI_MIN = 16384; // rows from which the multi-workgroup path is used
+constexpr int BOX_MULTI_GRID = 256;
+
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_box_step(const real *__restrict__ tx, const real *__restrict__ bl,
+                                                            const real *__restrict__ bu, int bsize,
+                                                            const real *t_warm, const real *r_box, BoxCtl *ctl,
+                                                            real *part, int it) {
+  __shared__ real red[SCSAMD_BLOCK / SCSAMD_WAVE];
+  const int tid = threadIdx.x, nwg = gridDim.x;
+  const real *x = tx + 1;
+  const real *rho = r_box ? r_box + 1 : nullptr;
+  real t;
+  if (it == 0) {
+    t = t_warm[0];
+    if (blockIdx.x == 0 && tid == 0) {
+      ctl->t[0] = t;
+      ctl->t_cur = t;
+      ctl->done = 0;
+    }
+  } else {
+    if (ctl->done) return;
+    const real t_prev = ctl->t[(it - 1) & 1];
+    const real *pg = part + (size_t)((it - 1) & 1) * 2 * BOX_MULTI_GRID, *ph = pg + BOX_MULTI_GRID;
+    real gt = reduce_partials_sum(pg, nwg, red);
+    real ht = reduce_partials_sum(ph, nwg, red);
+    const real rho_t = r_box ? (real)1 / r_box[0] : (real)1;
+    gt += rho_t * (t_prev - tx[0]);
+    ht += rho_t;
+    const real hm = ht > (real)1e-8 ? ht : (real)1e-8;
+    t = t_prev - gt / hm;
+    t = t > (real)0 ? t : (real)0;
+    const real hm6 = ht > (real)1e-6 ? ht : (real)1e-6;
+    const real tm = t > (real)1 ? t : (real)1;
+    const bool stop = absval(gt / hm6) < (real)1e-12 * tm || absval(t - t_prev) < (real)1e-11 * tm || it >= BOX_MAX_ITERS;
+    if (blockIdx.x == 0 && tid == 0) {
+      ctl->t[it & 1] = t;
+      ctl->t_cur = t;
+      if (stop) ctl->done = 1;
+    }
+    if (stop) return;
+  }
+  real gt = 0, ht = 0;
+  for (int j = blockIdx.x * SCSAMD_BLOCK + tid; j < bsize - 1; j += nwg * SCSAMD_BLOCK) {
+    const real r = rho ? (real)1 / rho[j] : (real)1;
+    const real xj = x[j], u = bu[j], lo = bl[j];
+    if (xj > t * u) {
+      gt += r * (t * u - xj) * u;
+      ht += r * u * u;
+    } else if (xj < t * lo) {
+      gt += r * (t * lo - xj) * lo;
+      ht += r * lo * lo;
+    }
+  }
+  gt = block_sum(gt, red);
+  ht = block_sum(ht, red);
+  if (tid == 0) {
+    real *pg = part + (size_t)(it & 1) * 2 * BOX_MULTI_GRID;
+    pg[blockIdx.x] = gt;
+    pg[BOX_MULTI_GRID + blockIdx.x] = ht;
+  }
+}
+
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_box_apply(real *tx, const real *__restrict__ bl,
+                                                             const real *__restrict__ bu, int bsize, real *t_warm,
+                                                             const BoxCtl *ctl) {
+  const real t = ctl->t_cur;
+  real *x = tx + 1;
+  for (int j = blockIdx.x * SCSAMD_BLOCK + threadIdx.x; j < bsize - 1; j += gridDim.x * SCSAMD_BLOCK) {
+    const real xj = x[j], u = bu[j], lo = bl[j];
+    if (xj > t * u) x[j] = t * u;
+    else if (xj < t * lo) x[j] = t * lo;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    tx[0] = t;
+    t_warm[0] = t;
+  }
+}
+
+// ----------------------------------------------------------------------------
 // second-order cones
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ void soc_decide(real v1, real s, real &head, real &mult) {
@@ -623,6 +715,12 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
     HIP_CHECK(hipStreamSynchronize(stream));
   }
   box_t.alloc(1);
+  box_multi = bsize - 1 >= BOX_MULTI_MIN;
+  if (const char *e = getenv("SCS_AMD_BOX_MULTI")) box_multi = atoi(e) != 0 && bsize > 1; // tests force either path
+  if (box_multi) {
+    box_part.alloc((size_t)4 * BOX_MULTI_GRID);
+    box_ctl.alloc(8); // one BoxCtl
+  }
   {
     const real one = 1; // cones.c:1560
     box_t.upload(&one, 1, stream);
@@ -705,9 +803,20 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
 void ConeDev::proj_primal(real *cw, const real *r_y) {
   if (z + l > 0)
     hipLaunchKernelGGL(k_zero_pos, dim3(small_grid(z + l)), dim3(SCSAMD_BLOCK), 0, stream, cw, z, l);
-  if (bsize > 0)
-    hipLaunchKernelGGL(k_box, dim3(1), dim3(BOX_THREADS), 0, stream, cw + box_off, bl.p, bu.p, bsize,
-                       box_t.p, r_y ? r_y + box_off : (const real *)nullptr);
+  if (bsize > 0) {
+    const real *rb = r_y ? r_y + box_off : (const real *)nullptr;
+    if (box_multi) {
+      const int g = std::max(1, std::min(BOX_MULTI_GRID, (bsize - 1 + 8 * SCSAMD_BLOCK - 1) / (8 * SCSAMD_BLOCK)));
+      BoxCtl *ctl = reinterpret_cast<BoxCtl *>(box_ctl.p);
+      for (int it = 0; it <= BOX_MAX_ITERS; ++it)
+        hipLaunchKernelGGL(k_box_step, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, cw + box_off, bl.p, bu.p, bsize, box_t.p,
+                           rb, ctl, box_part.p, it);
+      hipLaunchKernelGGL(k_box_apply, dim3(g), dim3(SCSAMD_BLOCK), 0, stream, cw + box_off, bl.p, bu.p, bsize, box_t.p,
+                         ctl);
+    } else {
+      hipLaunchKernelGGL(k_box, dim3(1), dim3(BOX_THREADS), 0, stream, cw + box_off, bl.p, bu.p, bsize, box_t.p, rb);
+    }
+  }
   if (n_tiny)
     hipLaunchKernelGGL(k_soc_tiny, dim3(small_grid(n_tiny)), dim3(SCSAMD_BLOCK), 0, stream, cw, tiny_off.p,
                        tiny_len.p, n_tiny);

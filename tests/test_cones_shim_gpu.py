@@ -101,3 +101,54 @@ def test_psd_warm_start_stays_accurate_over_a_drifting_sequence():
         worst = max(worst, np.abs(got - want).max() / max(1.0, np.abs(want).max()))
     lib.scs_amd_cone_finish(w)
     assert worst <= 1e-11, worst
+
+
+def _ref_lib():
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    return pyoracle.load_ref()
+
+
+@pytest.mark.parametrize("nb", [1000000, 20000])
+def test_large_box_cone_multi_workgroup_path_matches_reference(nb, monkeypatch):
+    """A box of 1e6 rows (every variable-bounded LP/QP from CVXPY has one) runs its Newton iteration as
+    chip-wide launches (k_box_step / k_box_apply, cones.hip) instead of one workgroup: same projection as
+    the reference's src/cones.c:1182-1245 with infinite bounds and the R_y metric, repeated calls
+    (warm-started t), and equal to the one-workgroup kernel."""
+    ref = _ref_lib()
+    lib = _lib()
+    rng = np.random.default_rng(5)
+    bu, bl = rng.uniform(0.1, 2.0, nb), -rng.uniform(0.1, 2.0, nb)
+    bu[::7] = 1e20   # |.| >= 1e15 means infinite (cones.c:1167-1175)
+    bl[::11] = -1e20
+    cone = dict(bu=bu, bl=bl)
+    r_y = rng.uniform(0.5, 3.0, nb + 1)
+    Tr = ref._scs_types
+    kr = capi.make_cone(cone, Tr)
+    wr = ref._scs_init_cone(C.byref(kr), nb + 1)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCS_AMD_BOX_MULTI", mode)
+        k = capi.make_cone(cone)
+        c = lib._scs_init_cone(C.byref(k), nb + 1)
+        assert c
+        res = []
+        for rep in range(3):
+            x0 = np.random.default_rng(100 + rep).standard_normal(nb + 1) * 2.0
+            x0[0] = abs(x0[0]) * (0.2 if rep != 1 else -1.0)  # rep 1: t < 0 exercises the clamp at zero
+            for r in (None, r_y):
+                x = x0.copy()
+                assert lib._scs_proj_dual_cone(x.ctypes.data_as(T.fp), c, None, r.ctypes.data_as(T.fp) if r is not None else None) == 0
+                res.append(x)
+                if mode == "1":
+                    want = x0.copy()
+                    assert ref._scs_proj_dual_cone(want.ctypes.data_as(Tr.fp), wr, None,
+                                                   r.ctypes.data_as(Tr.fp) if r is not None else None) == 0
+                    err = np.abs(x - want).max() / max(1.0, np.abs(want).max())
+                    assert err <= 1e-11, (nb, rep, r is not None, err)
+        outs[mode] = res
+        lib._scs_finish_cone(c)
+    ref._scs_finish_cone(wr)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())

@@ -114,8 +114,8 @@ def test_bench_cpu_baseline_worker_runs_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-worker", "socp:1:1500:10:1234:0:0:5:10"],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
     d = json.loads(out.stdout.strip().splitlines()[-1])
-    assert d["threads"] == 1 and d["n"] == 1500 and d["window"] == [5, 15]
-    assert d["its_per_s"] > 0 and d["window_s"] > 0, d
+    assert d["threads"] == 1 and d["n"] == 1500 and d["iter"] == 15  # ONE capped run of i0 + k iterations
+    assert d["solve_s"] > 0 and d["flavour"] == "libscsindir_ref.so", d
 
 
 def test_bench_gpus_flag_spawns_that_many_ranks():
