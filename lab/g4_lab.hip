@@ -1,0 +1,336 @@
+// lab/g4_lab.hip -- getting the matrix stream out of the gathering CU's in-order vector-memory queue
+// (not product code).  Background: profiles/r2_g2_lab.md -- on one CU the HBM stream of val/words and the
+// L2-resident gathers add up (38 + 37 us) instead of overlapping, because a CU's vector memory queue returns in
+// order and every L2-hit gather waits behind the HBM loads issued before it.
+//
+// Variants, all on the wave-owned-rows kernel (a lane owns 4 consecutive entries of a 256-entry step):
+//   S  scalar-cache prefetch: every wave touches the 24 lines of its own step k+D with s_load_dword (the scalar
+//      cache has its own path to L2), so the vector stream loads of step k+D hit L2
+//   R  role split: one workgroup per CU; in every XCD `npf` workgroups only touch the stream lines of the
+//      consumer workgroups of THEIR XCD `lead` steps ahead of the consumers' published progress
+//   M  Infinity-Cache policy: non-temporal loads/stores on the transposed product and the vector kernel, so
+//      that one matrix (120 MB) can stay in the 256 MB MALL across CG iterations
+//
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 lab/g4_lab.hip -o lab/g4_lab
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+template <typename T> T *dev(const std::vector<T> &h) { T *p; CK(hipMalloc(&p, (h.size() + 1024) * sizeof(T))); CK(hipMemset(p, 0, (h.size() + 1024) * sizeof(T))); CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return p; }
+template <typename T> T *devz(size_t n) { T *p; CK(hipMalloc(&p, (n + 1024) * sizeof(T))); CK(hipMemset(p, 0, (n + 1024) * sizeof(T))); return p; }
+
+struct G4 { int rows, cols, RW, CB, nunit; const int *ubeg, *uend; const unsigned *w; const double *val; };
+
+// nunit units of equal row count; entries of a unit sorted by column; unit starts aligned to 32 entries
+// (128 B of words, 256 B of values) so a 256-entry step is exactly 8 + 16 cache lines
+static G4 build4(int rows, int cols, const std::vector<int> &ptr, const std::vector<int> &idx, const std::vector<double> &val, int nunit) {
+  int CB = 1; while ((1 << CB) < cols) ++CB;
+  const int RW = (rows + nunit - 1) / nunit;
+  if ((long long)RW << CB > (1ll << 32)) { printf("packed word overflow RW=%d CB=%d\n", RW, CB); exit(1); }
+  std::vector<int> ubeg(nunit), uend(nunit);
+  const size_t nnz = ptr[rows];
+  const size_t cap = nnz + 32 * (size_t)nunit + 65536;
+  std::vector<unsigned> w(cap, 0u); std::vector<double> v(cap, 0.0);
+  std::vector<std::pair<unsigned long long, int>> tmp;
+  size_t q = 0;
+  for (int u = 0; u < nunit; ++u) {
+    const int r0 = std::min(rows, u * RW), r1 = std::min(rows, r0 + RW);
+    q = (q + 31) & ~(size_t)31; ubeg[u] = (int)q; tmp.clear();
+    for (int r = r0; r < r1; ++r) for (int k = ptr[r]; k < ptr[r + 1]; ++k) tmp.push_back({(unsigned long long)idx[k] << 20 | (unsigned)(r - r0), k});
+    std::sort(tmp.begin(), tmp.end());
+    for (auto &t : tmp) { const int k = t.second; w[q] = (unsigned)idx[k] | ((unsigned)(t.first & 0xfffff) << CB); v[q] = val[k]; ++q; }
+    uend[u] = (int)q;
+  }
+  return G4{rows, cols, RW, CB, nunit, dev(ubeg), dev(uend), dev(w), dev(v)};
+}
+static void freeg4(G4 &A) { CK(hipFree((void *)A.ubeg)); CK(hipFree((void *)A.uend)); CK(hipFree((void *)A.w)); CK(hipFree((void *)A.val)); }
+
+// touch 8 lines (128 B apart) starting at p through the scalar cache; results land in r[0..7] some time later
+#define SPF8(p, r)                                                                                                     \
+  asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x80\n\ts_load_dword %2, %8, 0x100\n\ts_load_dword %3, %8, 0x180\n\t" \
+               "s_load_dword %4, %8, 0x200\n\ts_load_dword %5, %8, 0x280\n\ts_load_dword %6, %8, 0x300\n\ts_load_dword %7, %8, 0x380"   \
+               : "=&s"(r[0]), "=&s"(r[1]), "=&s"(r[2]), "=&s"(r[3]), "=&s"(r[4]), "=&s"(r[5]), "=&s"(r[6]), "=&s"(r[7])                 \
+               : "s"(p))
+// wait for every outstanding scalar load; the registers stay reserved until here
+#define SWAIT8(r)                                                                                                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]), "+s"(r[4]), "+s"(r[5]), "+s"(r[6]), "+s"(r[7]))
+
+// MODE 0 normal; 1 no gather; 4 ceiling test: the stream is read from the first 512 entries of the unit over and over
+// (L2-resident, 1.5 MB per XCD) while the gathers keep the real access pattern (hashed columns in a window that moves
+// with the position in the unit) -- results are wrong by construction, only the time means something
+__device__ __forceinline__ void step_body(const G4 &A, const double *__restrict__ x, double *acc, int e0, int t, int lane, unsigned cmask, int MODE, int NT, int s = 0) {
+  const int e = e0 + lane * 4;
+  const int el = MODE == 4 ? s + ((e - s) & 511) : e;
+  uint4 w; double2 va, vb;
+  if (NT) {
+    const unsigned *pw = A.w + e; const double *pv = A.val + e;
+    w.x = __builtin_nontemporal_load(pw); w.y = __builtin_nontemporal_load(pw + 1); w.z = __builtin_nontemporal_load(pw + 2); w.w = __builtin_nontemporal_load(pw + 3);
+    va.x = __builtin_nontemporal_load(pv); va.y = __builtin_nontemporal_load(pv + 1); vb.x = __builtin_nontemporal_load(pv + 2); vb.y = __builtin_nontemporal_load(pv + 3);
+  } else {
+    w = *reinterpret_cast<const uint4 *>(A.w + el); va = *reinterpret_cast<const double2 *>(A.val + el); vb = *reinterpret_cast<const double2 *>(A.val + el + 2);
+  }
+  unsigned ww[4] = {w.x, w.y, w.z, w.w}; const double vv[4] = {va.x, va.y, vb.x, vb.y};
+  if (MODE == 4) {
+    const unsigned base = (unsigned)(((long long)(e - s) * A.cols) / max(1, t - s));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned h = (unsigned)(e + i) * 2654435761u; h ^= h >> 15; ww[i] = (ww[i] & ~cmask) | min((unsigned)A.cols - 1, base + (h & 0x3fff)); }
+  }
+  double xx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xx[i] = (MODE == 1) ? x[ww[i] & 63] : (e + i < t ? x[ww[i] & cmask] : 0.0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (e + i < t) __hip_atomic_fetch_add(acc + (ww[i] >> A.CB), vv[i] * xx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- S: wave-owned rows + scalar prefetch D steps ahead (D = 0: none).  MODE 1 = no gather.
+template <int WPB, int D, int MODE, int NT> __global__ __launch_bounds__(WPB * 64) void k_g4s(G4 A, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *accall = reinterpret_cast<double *>(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u = blockIdx.x * WPB + wave;
+  if (u >= A.nunit) return;
+  double *acc = accall + wave * A.RW;
+  for (int k = lane; k < A.RW; k += 64) acc[k] = 0.0;
+  const int s = __builtin_amdgcn_readfirstlane(A.ubeg[u]), t = __builtin_amdgcn_readfirstlane(A.uend[u]);
+  const unsigned cmask = (1u << A.CB) - 1;
+  unsigned ra[8], rb[8], rc[8], sink = 0, vsink = 0;
+  if (D > 0) {
+    // the first D steps are touched up front by one vector load each (the queue is empty at kernel start)
+    for (int j = 0; j < D; ++j)
+      if (lane < 24) {
+        const char *base = lane < 8 ? reinterpret_cast<const char *>(A.w + s + j * 256) + lane * 128 : reinterpret_cast<const char *>(A.val + s + j * 256) + (lane - 8) * 128;
+        vsink ^= *reinterpret_cast<const unsigned *>(base);
+      }
+  }
+  for (int e0 = s; e0 < t; e0 += 256) {
+    if (D > 0) {
+      // touch step k+D through the scalar cache (reading past the unit's end is harmless: the next unit / slack follows)
+      const int ep = e0 + D * 256;
+      const unsigned *pw = A.w + ep; const double *pv = A.val + ep; const double *pv2 = pv + 128;
+      SPF8(pw, ra); SPF8(pv, rb); SPF8(pv2, rc);
+    }
+    step_body(A, x, acc, e0, t, lane, cmask, MODE, NT, s);
+    if (D > 0) { SWAIT8(ra); SWAIT8(rb); SWAIT8(rc); sink ^= ra[0] ^ ra[7] ^ rb[3] ^ rc[5]; }
+  }
+  if (vsink == 0x9e3779b9u) y[1] += 1e-300;
+  const int r0 = u * A.RW, nr = max(0, min(A.RW, A.rows - r0));
+  for (int k = lane; k < nr; k += 64) y[r0 + k] = acc[k];
+  if (sink == 0x9e3779b9u && lane == 0) y[0] += 1e-300;
+}
+
+// ---- R: role split.  One workgroup of NW waves per CU (LDS request forces it).  ctl[x*64] = ticket counter of XCD x,
+// ctl[512 + x*512 + j] = steps finished by consumer wave j of XCD x.  Units of XCD x are x*upx .. x*upx+upx-1.
+// POL: 0 plain touch loads, 1 sc1 (agent-scope relaxed) touch loads
+template <int NW, int GATE> __global__ __launch_bounds__(NW * 64) void k_g4r(G4 A, const double *__restrict__ x, double *__restrict__ y, unsigned *ctl, int ncons, int upx, int lead, unsigned *census, int tstep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int sh_slot;
+  __shared__ unsigned sh_min;
+  double *accall = reinterpret_cast<double *>(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; // HW_REG_XCC_ID, bits [3:0]
+  if (threadIdx.x == 0) { sh_min = 0; sh_slot = (int)__hip_atomic_fetch_add(ctl + xcd * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __syncthreads();
+  const int slot = sh_slot;
+  if (census && threadIdx.x == 0) census[blockIdx.x] = (unsigned)(xcd << 16 | slot);
+  unsigned *prog = ctl + 512 + xcd * 512;
+  if (slot < ncons) {
+    const int j = slot * NW + wave;
+    if (j >= upx) return;
+    const int u = xcd * upx + j;
+    if (u >= A.nunit) return;
+    double *acc = accall + wave * A.RW;
+    for (int k = lane; k < A.RW; k += 64) acc[k] = 0.0;
+    const int s = __builtin_amdgcn_readfirstlane(A.ubeg[u]), t = __builtin_amdgcn_readfirstlane(A.uend[u]);
+    const unsigned cmask = (1u << A.CB) - 1;
+    int k = 0;
+    for (int e0 = s; e0 < t; e0 += 256) {
+      step_body(A, x, acc, e0, t, lane, cmask, 0, 0);
+      ++k;
+      if (GATE == 1 && lane == 0) __hip_atomic_store(prog + j, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (GATE == 1 && lane == 0) __hip_atomic_store(prog + j, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int r0 = u * A.RW, nr = max(0, min(A.RW, A.rows - r0));
+    for (int kk = lane; kk < nr; kk += 64) y[r0 + kk] = acc[kk];
+    return;
+  }
+  // ---- prefetcher pi of npf (placement-independent: whoever drew a ticket >= ncons in this XCD)
+  const int pi = slot - ncons, npf = max(1, 32 - ncons);
+  if (pi >= npf) return;
+  // step count bound: the longest unit of this XCD
+  int nsteps = 0;
+  for (int j = lane; j < upx; j += 64) { const int u = xcd * upx + j; if (u < A.nunit) nsteps = max(nsteps, (A.uend[u] - A.ubeg[u] + 255) / 256); }
+  for (int o = 32; o; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o));
+  const int nlines = upx * 24;                 // lines per step in this XCD
+  const int wv = pi * NW + wave, nwv = npf * NW; // this wave among the XCD's prefetch waves
+  unsigned sink = 0, prev[6] = {0, 0, 0, 0, 0, 0};
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int ts = 0; ts < nsteps; ++ts) {
+    if (GATE == 0) {
+      // time-paced: step ts may be touched from t0 + (ts - lead) * tstep (10 ns ticks of the device-wide clock)
+      const long long due = t0 + (long long)(ts - lead) * tstep;
+      for (int spin = 0; spin < 100000 && (long long)__builtin_amdgcn_s_memrealtime() < due; ++spin) __builtin_amdgcn_s_sleep(2);
+    } else if (ts >= lead) {
+      // progress-gated: wave 0 polls the XCD's consumer slots (one poller per prefetch workgroup) and broadcasts through LDS
+      const unsigned need = (unsigned)(ts - lead + 1);
+      if (wave == 0) {
+        for (int spin = 0; spin < 20000; ++spin) {
+          if (*(volatile unsigned *)&sh_min >= need) break;
+          unsigned mn = 0xffffffffu;
+          for (int j = lane; j < upx; j += 64) mn = min(mn, __hip_atomic_load(prog + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          for (int o = 32; o; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+          if (lane == 0) *(volatile unsigned *)&sh_min = mn;
+          if (mn >= need) break;
+          __builtin_amdgcn_s_sleep(32);
+        }
+      } else {
+        for (int spin = 0; spin < 2000000; ++spin) { if (*(volatile unsigned *)&sh_min >= need) break; __builtin_amdgcn_s_sleep(4); }
+      }
+    }
+    // up to 6 independent touch loads per wave per step; their values are folded one step later, so the loads
+    // of consecutive steps stay in flight together
+    unsigned cur[6];
+#pragma unroll
+    for (int q6 = 0; q6 < 6; ++q6) {
+      cur[q6] = 0;
+      const int l = (wv + q6 * nwv) * 64 + lane;
+      if (l < nlines) {
+        const int j = l / 24, q = l - j * 24, u = xcd * upx + j;
+        if (u < A.nunit) {
+          const int e = A.ubeg[u] + ts * 256;
+          if (e < A.uend[u]) {
+            const unsigned *p = q < 8 ? A.w + e + q * 32 : reinterpret_cast<const unsigned *>(A.val + e + (q - 8) * 16);
+            cur[q6] = *p;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q6 = 0; q6 < 6; ++q6) { sink ^= prev[q6]; prev[q6] = cur[q6]; }
+  }
+  if (sink == 0x9e3779b9u) y[0] += 1e-300;
+}
+
+__global__ void k_vec(const double2 *__restrict__ a, double2 *b, size_t n2) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) { double2 t = a[i], u = a[i + n2]; b[i] = double2{t.x + u.x, t.y + u.y}; } }
+__global__ void k_vec_nt(const double *__restrict__ a, double *b, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { double t = __builtin_nontemporal_load(a + i), u = __builtin_nontemporal_load(a + i + n); __builtin_nontemporal_store(t + u, b + i); } }
+__global__ void k_csr_scalar(int rows, const int *ptr, const int *idx, const double *val, const double *__restrict__ x, double *y) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    double acc = 0; for (int k = ptr[r]; k < ptr[r + 1]; ++k) acc += val[k] * x[idx[k]]; y[r] = acc; }
+}
+
+static void gen(int n, int m, int cn, std::vector<int> &Tp, std::vector<int> &Ti, std::vector<double> &Tx, std::vector<int> &Ap, std::vector<int> &Ai, std::vector<double> &Ax) {
+  size_t nnz = (size_t)n * cn; std::mt19937_64 rng(1);
+  Tp.resize(n + 1); Ti.resize(nnz); Tx.resize(nnz);
+  for (int j = 0; j < n; ++j) { Tp[j] = j * cn; int *r = &Ti[(size_t)j * cn];
+    for (;;) { for (int k = 0; k < cn; ++k) r[k] = (int)(rng() % m); std::sort(r, r + cn); if (std::adjacent_find(r, r + cn) == r + cn) break; }
+    for (int k = 0; k < cn; ++k) Tx[(size_t)j * cn + k] = (double)(rng() % 2001) / 1000.0 - 1.0; }
+  Tp[n] = (int)nnz;
+  Ap.assign(m + 1, 0); Ai.resize(nnz); Ax.resize(nnz);
+  for (size_t k = 0; k < nnz; ++k) Ap[Ti[k] + 1]++;
+  for (int i = 0; i < m; ++i) Ap[i + 1] += Ap[i];
+  std::vector<int> nx(Ap.begin(), Ap.end() - 1);
+  for (int j = 0; j < n; ++j) for (int k = Tp[j]; k < Tp[j + 1]; ++k) { int q = nx[Ti[k]]++; Ai[q] = j; Ax[q] = Tx[k]; }
+}
+
+struct Ev { hipEvent_t e; Ev() { CK(hipEventCreate(&e)); } };
+
+int main(int argc, char **argv) {
+  int n = argc > 1 ? atoi(argv[1]) : 1000000; int cn = 10; int m = 2 * n;
+  const char *only = argc > 2 ? argv[2] : "SRM";
+  std::vector<int> Tp, Ti, Ap, Ai; std::vector<double> Tx, Ax;
+  gen(n, m, cn, Tp, Ti, Tx, Ap, Ai, Ax);
+  const size_t nnz = Ti.size();
+  printf("n=%d m=%d nnz=%zu\n", n, m, nnz);
+  std::mt19937_64 rng(7);
+  std::vector<double> hx(m); for (auto &v : hx) v = (double)(rng() % 2001) / 1000.0 - 1.0;
+  int *dAp = dev(Ap), *dAi = dev(Ai), *dTp = dev(Tp), *dTi = dev(Ti);
+  double *dAx = dev(Ax), *dTx = dev(Tx), *dx = dev(hx), *dy = devz<double>(m), *dref = devz<double>(m);
+  hipLaunchKernelGGL(k_csr_scalar, dim3(8192), dim3(256), 0, 0, m, dAp, dAi, dAx, dx, dref);
+  std::vector<double> hrefA(m), hrefT(n), hy(m);
+  CK(hipMemcpy(hrefA.data(), dref, (size_t)m * 8, hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(k_csr_scalar, dim3(8192), dim3(256), 0, 0, n, dTp, dTi, dTx, dx, dref);
+  CK(hipMemcpy(hrefT.data(), dref, (size_t)n * 8, hipMemcpyDeviceToHost));
+  CK(hipFree(dAp)); CK(hipFree(dAi)); CK(hipFree(dTp)); CK(hipFree(dTi)); CK(hipFree(dAx)); CK(hipFree(dTx));
+  double *dv1 = devz<double>(8 << 20), *dv2 = devz<double>(4 << 20);
+  unsigned *ctl = devz<unsigned>(512 + 8 * 512), *census = devz<unsigned>(4096);
+  const long long bA = (long long)nnz * 12 + (m + 1) * 4LL + n * 8LL + m * 8LL, bT = (long long)nnz * 12 + (n + 1) * 4LL + m * 8LL + n * 8LL;
+  auto kV = [&] { hipLaunchKernelGGL(k_vec, dim3(512), dim3(256), 0, 0, (const double2 *)dv1, (double2 *)dv2, (size_t)(2 << 20)); };
+  auto kVnt = [&] { hipLaunchKernelGGL(k_vec_nt, dim3(512), dim3(256), 0, 0, (const double *)dv1, dv2, (size_t)(4 << 20)); };
+  // realistic sequence (A product, At product, 96 MB vector kernel) so neither matrix stays in the Infinity Cache
+  auto run = [&](const char *tag, auto kA, auto kT, auto kVV) {
+    CK(hipMemset(dy, 0, (size_t)m * 8));
+    kA(); CK(hipDeviceSynchronize()); CK(hipMemcpy(hy.data(), dy, (size_t)m * 8, hipMemcpyDeviceToHost)); double eA = 0; for (int i = 0; i < m; ++i) eA = std::max(eA, fabs(hy[i] - hrefA[i]));
+    CK(hipMemset(dy, 0, (size_t)m * 8));
+    kT(); CK(hipDeviceSynchronize()); CK(hipMemcpy(hy.data(), dy, (size_t)n * 8, hipMemcpyDeviceToHost)); double eT = 0; for (int i = 0; i < n; ++i) eT = std::max(eT, fabs(hy[i] - hrefT[i]));
+    Ev e0, e1, e2, e3; double tA = 0, tT = 0, tV = 0; const int reps = 20;
+    for (int i = 0; i < 3; ++i) { kA(); kT(); kVV(); }
+    for (int i = 0; i < reps; ++i) { CK(hipEventRecord(e0.e)); kA(); CK(hipEventRecord(e1.e)); kT(); CK(hipEventRecord(e2.e)); kVV(); CK(hipEventRecord(e3.e)); CK(hipEventSynchronize(e3.e));
+      float ms; CK(hipEventElapsedTime(&ms, e0.e, e1.e)); tA += ms; CK(hipEventElapsedTime(&ms, e1.e, e2.e)); tT += ms; CK(hipEventElapsedTime(&ms, e2.e, e3.e)); tV += ms; }
+    tA *= 1e3 / reps; tT *= 1e3 / reps; tV *= 1e3 / reps;
+    printf("%-44s A %6.1f us (%4.1f%%)  At %6.1f us (%4.1f%%)  vec %5.1f | pair %6.1f us => %4.1f%% of 8 TB/s   err %.0e %.0e\n", tag, tA, bA / tA / 1e3 / 80, tT, bT / tT / 1e3 / 80, tV, tA + tT,
+           (bA + bT) / (tA + tT) / 1e3 / 80, eA, eT);
+    fflush(stdout);
+  };
+
+  if (strchr(only, 'S') || strchr(only, 'M')) {
+    const int WPB = 4, nunit = 2048;
+    G4 A = build4(m, n, Ap, Ai, Ax, nunit), At = build4(n, m, Tp, Ti, Tx, nunit);
+    const size_t lA = (size_t)WPB * A.RW * 8, lT = (size_t)WPB * At.RW * 8; const int g = nunit / WPB;
+    printf("-- S/M: %d units, rwA %d rwT %d, %d workgroups of %d waves\n", nunit, A.RW, At.RW, g, WPB);
+    auto mk = [&](auto kern, const G4 &M, size_t l) { CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lA, lT))); return [=] { hipLaunchKernelGGL(kern, dim3(g), dim3(WPB * 64), l, 0, M, dx, dy); }; };
+    auto mk8 = [&](auto kern, const G4 &M, size_t l) { CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lA, lT) * 2)); return [=] { hipLaunchKernelGGL(kern, dim3(g / 2), dim3(8 * 64), 2 * l, 0, M, dx, dy); }; };
+    if (strchr(only, 'S')) {
+      run("S D0 (no prefetch)", mk(k_g4s<4, 0, 0, 0>, A, lA), mk(k_g4s<4, 0, 0, 0>, At, lT), kV);
+      run("S D0 nogather", mk(k_g4s<4, 0, 1, 0>, A, lA), mk(k_g4s<4, 0, 1, 0>, At, lT), kV);
+      run("S D0 CEILING: stream from L2 (wrapped), real gather pattern", mk(k_g4s<4, 0, 4, 0>, A, lA), mk(k_g4s<4, 0, 4, 0>, At, lT), kV);
+      run("S D0 WPB8 CEILING", mk8(k_g4s<8, 0, 4, 0>, A, lA), mk8(k_g4s<8, 0, 4, 0>, At, lT), kV);
+      run("S D0 WPB8 normal", mk8(k_g4s<8, 0, 0, 0>, A, lA), mk8(k_g4s<8, 0, 0, 0>, At, lT), kV);
+      if (getenv("G4_QUICK")) { freeg4(A); freeg4(At); return 0; }
+      run("S D1 scalar prefetch", mk(k_g4s<4, 1, 0, 0>, A, lA), mk(k_g4s<4, 1, 0, 0>, At, lT), kV);
+      run("S D2 scalar prefetch", mk(k_g4s<4, 2, 0, 0>, A, lA), mk(k_g4s<4, 2, 0, 0>, At, lT), kV);
+      run("S D3 scalar prefetch", mk(k_g4s<4, 3, 0, 0>, A, lA), mk(k_g4s<4, 3, 0, 0>, At, lT), kV);
+      run("S D4 scalar prefetch", mk(k_g4s<4, 4, 0, 0>, A, lA), mk(k_g4s<4, 4, 0, 0>, At, lT), kV);
+      run("S D6 scalar prefetch", mk(k_g4s<4, 6, 0, 0>, A, lA), mk(k_g4s<4, 6, 0, 0>, At, lT), kV);
+      run("S D2 scalar prefetch nogather", mk(k_g4s<4, 2, 1, 0>, A, lA), mk(k_g4s<4, 2, 1, 0>, At, lT), kV);
+      run("S D4 scalar prefetch nogather", mk(k_g4s<4, 4, 1, 0>, A, lA), mk(k_g4s<4, 4, 1, 0>, At, lT), kV);
+    }
+    if (strchr(only, 'M')) {
+      run("M baseline (all default policy)", mk(k_g4s<4, 0, 0, 0>, A, lA), mk(k_g4s<4, 0, 0, 0>, At, lT), kV);
+      run("M At stream nt", mk(k_g4s<4, 0, 0, 0>, A, lA), mk(k_g4s<4, 0, 0, 1>, At, lT), kV);
+      run("M At stream nt + vec nt", mk(k_g4s<4, 0, 0, 0>, A, lA), mk(k_g4s<4, 0, 0, 1>, At, lT), kVnt);
+      run("M vec nt only", mk(k_g4s<4, 0, 0, 0>, A, lA), mk(k_g4s<4, 0, 0, 0>, At, lT), kVnt);
+      run("M A and At stream nt + vec nt", mk(k_g4s<4, 0, 0, 1>, A, lA), mk(k_g4s<4, 0, 0, 1>, At, lT), kVnt);
+    }
+    freeg4(A); freeg4(At);
+    // same with 8-wave and 16-wave workgroups, one per CU (the R geometry without prefetchers is covered below)
+  }
+
+  if (strchr(only, 'R')) {
+    auto role = [&](auto kern, int NW, int ncons, int lead, int tstep, const char *pol) {
+      const int upx = ncons * NW, nunit = 8 * upx;
+      G4 A = build4(m, n, Ap, Ai, Ax, nunit), At = build4(n, m, Tp, Ti, Tx, nunit);
+      const size_t lA = std::max<size_t>((size_t)NW * A.RW * 8, 84 * 1024), lT = std::max<size_t>((size_t)NW * At.RW * 8, 84 * 1024);
+      CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lA, lT)));
+      const size_t ctlb = (512 + 8 * 512) * sizeof(unsigned);
+      auto kA = [&] { CK(hipMemsetAsync(ctl, 0, ctlb, 0)); hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lA, 0, A, dx, dy, ctl, ncons, upx, lead, census, tstep); };
+      auto kT = [&] { CK(hipMemsetAsync(ctl, 0, ctlb, 0)); hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lT, 0, At, dx, dy, ctl, ncons, upx, lead, (unsigned *)nullptr, tstep); };
+      char tag[128]; snprintf(tag, sizeof tag, "R NW%-2d cons %2d/32 lead %d %s tstep %d0ns", NW, ncons, lead, pol, tstep);
+      run(tag, kA, kT, kV);
+      static bool shown = false;
+      if (!shown) { shown = true; std::vector<unsigned> hc(256); CK(hipMemcpy(hc.data(), census, 256 * 4, hipMemcpyDeviceToHost)); int per[8] = {0}, same = 0; for (int b = 0; b < 256; ++b) { per[hc[b] >> 16 & 7]++; same += (int)((hc[b] >> 16 & 7) == (unsigned)(b % 8)); }
+        printf("   census: workgroups per XCD %d %d %d %d %d %d %d %d ; block b on XCD b%%8: %d of 256\n", per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7], same); }
+      freeg4(A); freeg4(At);
+    };
+    role(k_g4r<8, 0>, 8, 32, 2, 0, "none ");   // control: no prefetchers
+    for (int ncons : {30, 28}) for (int lead : {1, 2, 4}) role(k_g4r<8, 1>, 8, ncons, lead, 0, "progress");
+    for (int ncons : {30, 28}) for (int lead : {2}) for (int tstep : {200, 250, 300, 350, 400}) role(k_g4r<8, 0>, 8, ncons, lead, tstep, "timed");
+    for (int ncons : {29}) for (int lead : {1, 3}) for (int tstep : {250, 300, 350}) role(k_g4r<8, 0>, 8, ncons, lead, tstep, "timed");
+  }
+  return 0;
+}
