@@ -633,6 +633,11 @@ OrCone *or_cone_init(int m, int z, int l, int bsize, const double *bl, const dou
   for (j = 0; j < bsize - 1; ++j) {
     const double *Db = D ? D + z + l : NULL;
     double f = Db ? Db[j + 1] / Db[0] : 1.0;
+    if (!Db) { /* cones.c:1561: normalize_box_cone only runs when a scaling exists */
+      c->bu[j] = bu[j];
+      c->bl[j] = bl[j];
+      continue;
+    }
     c->bu[j] = bu[j] >= 1e15 ? INFINITY : bu[j] * f;
     c->bl[j] = bl[j] <= -1e15 ? -INFINITY : bl[j] * f;
   }

@@ -700,11 +700,18 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   box_off = z + l;
   int off = z + l;
   if (bsize > 1) {
-    // normalize_box_cone (cones.c:1161-1177) applied to a private copy
+    // normalize_box_cone (cones.c:1161-1177) applied to a private copy.  The reference only calls it when a
+    // scaling exists (cones.c:1561: `if (scal)`), so without one the bounds are used exactly as given -- a
+    // "1e20 = infinite" bound then stays the finite number 1e20, as in the reference
     std::vector<real> hl(bsize - 1), hu(bsize - 1);
     const real *Db = D ? D + box_off : nullptr;
     for (int j = 0; j < bsize - 1; ++j) {
-      const real f = Db ? Db[j + 1] / Db[0] : (real)1;
+      if (!Db) {
+        hu[j] = k->bu[j];
+        hl[j] = k->bl[j];
+        continue;
+      }
+      const real f = Db[j + 1] / Db[0];
       hu[j] = k->bu[j] >= (real)MAX_BOX_VAL ? (real)INFINITY : k->bu[j] * f;
       hl[j] = k->bl[j] <= (real)-MAX_BOX_VAL ? (real)-INFINITY : k->bl[j] * f;
     }

@@ -122,33 +122,41 @@ def test_large_box_cone_multi_workgroup_path_matches_reference(nb, monkeypatch):
     bu, bl = rng.uniform(0.1, 2.0, nb), -rng.uniform(0.1, 2.0, nb)
     bu[::7] = 1e20   # |.| >= 1e15 means infinite (cones.c:1167-1175)
     bl[::11] = -1e20
-    cone = dict(bu=bu, bl=bl)
     r_y = rng.uniform(0.5, 3.0, nb + 1)
+    # the reference turns |bound| >= 1e15 into +-inf only inside normalize_box_cone, i.e. only when a scaling is
+    # passed (cones.c:1561, which also rescales the caller's arrays in place: every library gets its own copy);
+    # without one 1e20 stays a finite bound.  Both behaviours are compared.
+    D = rng.uniform(0.5, 2.0, nb + 1)
     Tr = ref._scs_types
-    kr = capi.make_cone(cone, Tr)
-    wr = ref._scs_init_cone(C.byref(kr), nb + 1)
+    ref._scs_proj_dual_cone.argtypes = [Tr.fp, C.c_void_p, C.c_void_p, Tr.fp]
     outs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("SCS_AMD_BOX_MULTI", mode)
-        k = capi.make_cone(cone)
-        c = lib._scs_init_cone(C.byref(k), nb + 1)
-        assert c
-        res = []
-        for rep in range(3):
-            x0 = np.random.default_rng(100 + rep).standard_normal(nb + 1) * 2.0
-            x0[0] = abs(x0[0]) * (0.2 if rep != 1 else -1.0)  # rep 1: t < 0 exercises the clamp at zero
-            for r in (None, r_y):
-                x = x0.copy()
-                assert lib._scs_proj_dual_cone(x.ctypes.data_as(T.fp), c, None, r.ctypes.data_as(T.fp) if r is not None else None) == 0
-                res.append(x)
-                if mode == "1":
-                    want = x0.copy()
-                    assert ref._scs_proj_dual_cone(want.ctypes.data_as(Tr.fp), wr, None,
-                                                   r.ctypes.data_as(Tr.fp) if r is not None else None) == 0
-                    err = np.abs(x - want).max() / max(1.0, np.abs(want).max())
-                    assert err <= 1e-11, (nb, rep, r is not None, err)
-        outs[mode] = res
-        lib._scs_finish_cone(c)
-    ref._scs_finish_cone(wr)
-    for a, b in zip(outs["1"], outs["0"]):
-        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
+    for use_scal in (True, False):
+        kr = capi.make_cone(dict(bu=bu.copy(), bl=bl.copy()), Tr)
+        wr = ref._scs_init_cone(C.byref(kr), nb + 1)
+        scal = ScsScaling(D.ctypes.data_as(T.fp), None, nb + 1, 0, 1.0, 1.0) if use_scal else None
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SCS_AMD_BOX_MULTI", mode)
+            k = capi.make_cone(dict(bu=bu.copy(), bl=bl.copy()))
+            c = lib._scs_init_cone(C.byref(k), nb + 1)
+            assert c
+            res = []
+            for rep in range(3):
+                x0 = np.random.default_rng(100 + rep).standard_normal(nb + 1) * 2.0
+                x0[0] = abs(x0[0]) * (0.2 if rep != 1 else -1.0)  # rep 1: t < 0 exercises the clamp at zero
+                for r in (None, r_y):
+                    x = x0.copy()
+                    assert lib._scs_proj_dual_cone(x.ctypes.data_as(T.fp), c, C.byref(scal) if scal else None,
+                                                   r.ctypes.data_as(T.fp) if r is not None else None) == 0
+                    res.append(x)
+                    if mode == "1":
+                        want = x0.copy()
+                        assert ref._scs_proj_dual_cone(want.ctypes.data_as(Tr.fp), wr, C.byref(scal) if scal else None,
+                                                       r.ctypes.data_as(Tr.fp) if r is not None else None) == 0
+                        err = np.abs(x - want).max() / max(1.0, np.abs(want).max())
+                        assert err <= 1e-11, (nb, use_scal, rep, r is not None, err)
+            outs[(use_scal, mode)] = res
+            lib._scs_finish_cone(c)
+        ref._scs_finish_cone(wr)
+    for use_scal in (True, False):
+        for a, b in zip(outs[(use_scal, "1")], outs[(use_scal, "0")]):
+            assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
