@@ -125,6 +125,77 @@ template <int WPB, int D, int MODE, int NT> __global__ __launch_bounds__(WPB * 6
   if (sink == 0x9e3779b9u && lane == 0) y[0] += 1e-300;
 }
 
+
+// ---- P: three-stage software pipeline per wave: stream loads of step k+2 | gathers of step k+1 | LDS adds of step k.
+// Every wait is for something issued a whole iteration earlier (vmcnt counts in order), so a wave keeps
+// 3 stream loads + 4..8 gathers in flight all the time instead of draining its queue twice per step.
+struct Strm { uint4 w; double2 va, vb; };
+__device__ __forceinline__ Strm ld_strm(const G4 &A, int e, int s, int MODE) {
+  const int el = MODE == 4 ? s + ((e - s) & 511) : e;
+  Strm r; r.w = *reinterpret_cast<const uint4 *>(A.w + el); r.va = *reinterpret_cast<const double2 *>(A.val + el); r.vb = *reinterpret_cast<const double2 *>(A.val + el + 2); return r;
+}
+__device__ __forceinline__ void fix_cols(const G4 &A, Strm &q, int e, int s, int t, unsigned cmask, int MODE) {
+  if (MODE != 4) return;
+  const unsigned base = (unsigned)(((long long)(e - s) * A.cols) / max(1, t - s));
+  unsigned *ww = &q.w.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { unsigned h = (unsigned)(e + i) * 2654435761u; h ^= h >> 15; ww[i] = (ww[i] & ~cmask) | min((unsigned)A.cols - 1, base + (h & 0x3fff)); }
+}
+template <int WPB, int MODE> __global__ __launch_bounds__(WPB * 64) void k_g4p(G4 A, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *accall = reinterpret_cast<double *>(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u = blockIdx.x * WPB + wave;
+  if (u >= A.nunit) return;
+  double *acc = accall + wave * A.RW;
+  for (int k = lane; k < A.RW; k += 64) acc[k] = 0.0;
+  const int s = __builtin_amdgcn_readfirstlane(A.ubeg[u]), t = __builtin_amdgcn_readfirstlane(A.uend[u]);
+  const unsigned cmask = (1u << A.CB) - 1;
+  // reading up to two steps past the unit's end is harmless (next unit / zero slack): entries >= t are
+  // neutralised by value (word 0, value 0: adds 0.0 to the unit's row 0), so the loop body has no branches and
+  // the compiler never drains the queue at a join point
+  auto mask = [&](Strm &q, int e) {
+    unsigned *ww = &q.w.x; double *vv = &q.va.x; double *vw = &q.vb.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (e + i >= t) { ww[i] = 0u; (i < 2 ? vv[i] : vw[i - 2]) = 0.0; }
+  };
+  int e = s + lane * 4;
+  Strm q1 = ld_strm(A, e, s, MODE);           // step 0
+  Strm q2 = ld_strm(A, e + 256, s, MODE);     // step 1
+  fix_cols(A, q1, e, s, t, cmask, MODE); mask(q1, e);
+  double x1[4];
+  { const unsigned *ww = &q1.w.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x1[i] = x[ww[i] & cmask]; }
+  double x2[4], x3[4];
+  Strm q3;
+  // one step: QC <- stream of step k+2 | XB <- gathers of step k+1 (from QB) | adds of step k (QA, XA).
+  // The roles rotate through three register sets (unrolled by three), so no loaded value is ever copied --
+  // a copy would make the compiler wait for it
+#define G4P_STEP(QA, XA, QB, XB, QC)                                                                                  \
+  {                                                                                                                   \
+    QC = ld_strm(A, e + 512, s, MODE);                                                                                \
+    fix_cols(A, QB, e + 256, s, t, cmask, MODE);                                                                      \
+    mask(QB, e + 256);                                                                                                \
+    { const unsigned *ww = &QB.w.x;                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) XB[i] = x[ww[i] & cmask]; }                                       \
+    { const unsigned *ww = &QA.w.x; const double vv[4] = {QA.va.x, QA.va.y, QA.vb.x, QA.vb.y};                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+        __hip_atomic_fetch_add(acc + (ww[i] >> A.CB), vv[i] * XA[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } \
+    e += 256; e0 += 256;                                                                                              \
+  }
+  for (int e0 = s; e0 < t;) {
+    G4P_STEP(q1, x1, q2, x2, q3);
+    if (e0 >= t) break;
+    G4P_STEP(q2, x2, q3, x3, q1);
+    if (e0 >= t) break;
+    G4P_STEP(q3, x3, q1, x1, q2);
+  }
+#undef G4P_STEP
+  const int r0 = u * A.RW, nr = max(0, min(A.RW, A.rows - r0));
+  for (int k = lane; k < nr; k += 64) y[r0 + k] = acc[k];
+}
+
 // ---- R: role split.  One workgroup of NW waves per CU (LDS request forces it).  ctl[x*64] = ticket counter of XCD x,
 // ctl[512 + x*512 + j] = steps finished by consumer wave j of XCD x.  Units of XCD x are x*upx .. x*upx+upx-1.
 // POL: 0 plain touch loads, 1 sc1 (agent-scope relaxed) touch loads
@@ -288,6 +359,9 @@ int main(int argc, char **argv) {
     if (strchr(only, 'S')) {
       run("S D0 (no prefetch)", mk(k_g4s<4, 0, 0, 0>, A, lA), mk(k_g4s<4, 0, 0, 0>, At, lT), kV);
       run("S D0 nogather", mk(k_g4s<4, 0, 1, 0>, A, lA), mk(k_g4s<4, 0, 1, 0>, At, lT), kV);
+      run("P 3-stage pipeline WPB4", mk(k_g4p<4, 0>, A, lA), mk(k_g4p<4, 0>, At, lT), kV);
+      run("P 3-stage pipeline WPB8", mk8(k_g4p<8, 0>, A, lA), mk8(k_g4p<8, 0>, At, lT), kV);
+      run("P 3-stage pipeline WPB4 CEILING (stream from L2)", mk(k_g4p<4, 4>, A, lA), mk(k_g4p<4, 4>, At, lT), kV);
       run("S D0 CEILING: stream from L2 (wrapped), real gather pattern", mk(k_g4s<4, 0, 4, 0>, A, lA), mk(k_g4s<4, 0, 4, 0>, At, lT), kV);
       run("S D0 WPB8 CEILING", mk8(k_g4s<8, 0, 4, 0>, A, lA), mk8(k_g4s<8, 0, 4, 0>, At, lT), kV);
       run("S D0 WPB8 normal", mk8(k_g4s<8, 0, 0, 0>, A, lA), mk8(k_g4s<8, 0, 0, 0>, At, lT), kV);

@@ -27,7 +27,7 @@ struct ConeDev {
   DevBuf<real> tile_part;   // per-tile sum of squares of the tail
   DevBuf<real> big_coef;    // per big cone: [head, tail multiplier]
   // PSD cones
-  int n_psd = 0, psd_kmax = 0;
+  int n_psd = 0, psd_kmax = 0, psd_lds_kmax = 0;
   DevBuf<int> psd_off, psd_k;
   DevBuf<real> psd_work;    // global scratch for blocks that do not fit in LDS
   DevBuf<real> psd_vprev;   // per block: eigenbasis of the previous projection (warm start; k <= 72)

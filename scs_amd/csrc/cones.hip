@@ -375,7 +375,7 @@ __device__ __forceinline__ void psd_lds_matmul(real *C, const real *L, const rea
 // whenever vprev is given.  The host restarts cold every PSD_WARM_RESET calls.
 __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *__restrict__ psd_off,
                                                             const int *__restrict__ psd_k, real *scratch,
-                                                            int kmax, int use_lds, int *status, real *vprev,
+                                                            int kmax, int lds_kmax, int *status, real *vprev,
                                                             int warm) {
   // all scratch lives in the dynamic region (16-byte aligned base, guide G17):
   // [rot_cs (c,s pairs) | rot_pq (p,q pairs) | red | step flags | A | V]
@@ -407,8 +407,13 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   const int npairs = K2 / 2;
   const int ld = K2 | 1; // odd leading dimension: conflict-free row and column walks
   const int K2m = (kmax + 1) & ~1, ldm = K2m | 1;
+  const bool use_lds = k <= lds_kmax; // per block: small blocks stay in LDS next to a large one in the same program
   real *A = use_lds ? lds_mat : scratch + (size_t)cone * 2 * K2m * ldm;
   real *V = A + (size_t)K2 * ld;
+  // element (r, c): in LDS row-major with an odd leading dimension (lanes that walk rows hit distinct banks); in the
+  // global-memory scratch of large blocks column-major, so the same lanes touch consecutive addresses (the 2x2-block
+  // pass and the eigenvector update walk rows -- row-major there cost a 128-byte line per 8-byte access)
+  auto MI = [&](int r, int c) { return use_lds ? r * ld + c : c * ld + r; };
   const real sqrt2 = sqrt((real)2);
   // unpack: full symmetric, diagonal * sqrt(2)  (cones.c:1018-1025)
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
@@ -433,8 +438,8 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         }
       }
     }
-    A[i * ld + j] = v;
-    V[i * ld + j] = i == j ? (real)1 : (real)0;
+    A[MI(i, j)] = v;
+    V[MI(i, j)] = i == j ? (real)1 : (real)0;
   }
   __syncthreads();
   real *Vg = vprev ? vprev + (size_t)cone * K2m * ldm : nullptr;
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   }
   real fro = 0;
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
-    const real v = A[(e / K2) * ld + (e % K2)];
+    const real v = A[MI(e % K2, e / K2)];
     fro += v * v;
   }
   fro = sqrt(block_sum(fro, red));
@@ -492,13 +497,13 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
             q = t;
           }
           real c = 1, s = 0;
-          const real apq = A[p * ld + q];
+          const real apq = A[MI(p, q)];
           const real aa = absval(apq);
           if (q < k) offmax = aa > offmax ? aa : offmax;
           if (q < k && aa > thr) {
             // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written
             // without the first division: t = sgn(d) b / (|d| + sqrt(d^2 + b^2)), d = aqq - app, b = 2 apq
-            const real d = A[q * ld + q] - A[p * ld + p], b = (real)2 * apq;
+            const real d = A[MI(q, q)] - A[MI(p, p)], b = (real)2 * apq;
             const real h = sqrt(d * d + b * b);
             const real t = (d >= 0 ? b : -b) / (absval(d) + h);
             c = rsqrt(t * t + (real)1);
@@ -523,20 +528,26 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
             const RotCS r1 = rot_cs[P], r2 = rot_cs[Q];
             const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
             const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
-            const real a11 = A[p1 * ld + p2], a12 = A[p1 * ld + q2], a21 = A[q1 * ld + p2], a22 = A[q1 * ld + q2];
+            const int i11 = MI(p1, p2), i12 = MI(p1, q2), i21 = MI(q1, p2), i22 = MI(q1, q2);
+            const real a11 = A[i11], a12 = A[i12], a21 = A[i21], a22 = A[i22];
             const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
             const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
-            A[p1 * ld + p2] = c2 * r11 - s2 * r12;
-            A[p1 * ld + q2] = s2 * r11 + c2 * r12;
-            A[q1 * ld + p2] = c2 * r21 - s2 * r22;
-            A[q1 * ld + q2] = s2 * r21 + c2 * r22;
+            // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is
+            // left otherwise is rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the
+            // convergence threshold and kept the sweeps going to the cap)
+            const bool own = P == Q && s1 != (real)0;
+            A[i11] = c2 * r11 - s2 * r12;
+            A[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
+            A[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
+            A[i22] = s2 * r21 + c2 * r22;
           } else {
             const int f = e - nblk, Q = f / K2, i = f % K2; // consecutive rows: stride ld
             const int2 pq2 = rot_pq[Q];
             const RotCS r2 = rot_cs[Q];
-            const real vp = V[i * ld + pq2.x], vq = V[i * ld + pq2.y];
-            V[i * ld + pq2.x] = r2.c * vp - r2.s * vq;
-            V[i * ld + pq2.y] = r2.s * vp + r2.c * vq;
+            const int ip = MI(i, pq2.x), iq = MI(i, pq2.y);
+            const real vp = V[ip], vq = V[iq];
+            V[ip] = r2.c * vp - r2.s * vq;
+            V[iq] = r2.s * vp + r2.c * vq;
           }
         }
         __syncthreads();
@@ -549,11 +560,11 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044); lambda = diag(A)
   __syncthreads();
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
-    const int i = e / K2, cidx = e % K2;
-    const real lam = A[cidx * ld + cidx];
-    const real vv = V[i * ld + cidx];
+    const int i = use_lds ? e / K2 : e % K2, cidx = use_lds ? e % K2 : e / K2;
+    const real lam = A[MI(cidx, cidx)];
+    const real vv = V[MI(i, cidx)];
     if (Vg) Vg[i * ld + cidx] = vv; // the eigenbasis, for the next projection of this cone
-    V[i * ld + cidx] = vv * ((cidx < k && lam > (real)0) ? sqrt(lam) : (real)0);
+    V[MI(i, cidx)] = vv * ((cidx < k && lam > (real)0) ? sqrt(lam) : (real)0);
   }
   __syncthreads();
   // X+ = W W', lower triangle only, repack with diagonal / sqrt(2)  (cones.c:1052-1063)
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         ra = ((rem - 1) & 1) ? r + nn : r;
       }
       real acc = 0;
-      for (int cidx = 0; cidx < k; ++cidx) acc += V[ra * ld + cidx] * V[rb * ld + cidx];
+      for (int cidx = 0; cidx < k; ++cidx) acc += V[MI(ra, cidx)] * V[MI(rb, cidx)];
       X[e] = acc * scale;
     }
     return;
@@ -595,8 +606,8 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       const int ra = ti * 16 + li, rb = tj * 16 + li;
       for (int ks = 0; ks < ksteps; ++ks) {
         const int kc = ks * 4 + lk;
-        const double av = (ra < k && kc < K2) ? V[ra * ld + kc] : 0.0;
-        const double bv = (rb < k && kc < K2) ? V[rb * ld + kc] : 0.0;
+        const double av = (ra < k && kc < K2) ? V[MI(ra, kc)] : 0.0;
+        const double bv = (rb < k && kc < K2) ? V[MI(rb, kc)] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       }
       const int i = j + rem;
       real acc = 0;
-      for (int cidx = 0; cidx < k; ++cidx) acc += V[i * ld + cidx] * V[j * ld + cidx];
+      for (int cidx = 0; cidx < k; ++cidx) acc += V[MI(i, cidx)] * V[MI(j, cidx)];
       if (i == j) acc *= inv_sqrt2;
       X[e] = acc;
     }
@@ -790,6 +801,11 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   n_psd = (int)poff.size();
   up(psd_off, poff);
   up(psd_k, pk);
+  psd_lds_kmax = 0;
+  for (int kk : pk) {
+    const int ka = kk < 0 ? -kk : kk;
+    if (ka <= PSD_LDS_KMAX) psd_lds_kmax = std::max(psd_lds_kmax, ka);
+  }
   if (n_psd && psd_kmax > PSD_LDS_KMAX)
     psd_work.alloc((size_t)n_psd * 2 * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
   psd_calls = 0;
@@ -837,17 +853,17 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
                        tile_cone.p, big_off.p, big_coef.p, n_tiles);
   }
   if (n_psd) {
-    const int use_lds = psd_kmax <= PSD_LDS_KMAX;
-    const int K2m = (psd_kmax + 1) & ~1;
+    const int lds_kmax = std::min(psd_kmax, psd_lds_kmax); // largest block order held in LDS
+    const int K2l = (lds_kmax + 1) & ~1;
     const bool carry = psd_vprev.p != nullptr;
-    const size_t lds = PSD_LDS_HEADER + (use_lds ? (size_t)(carry ? 3 : 2) * K2m * (K2m | 1) * sizeof(real) : 0);
+    const size_t lds = PSD_LDS_HEADER + (size_t)(carry ? 3 : 2) * K2l * (K2l | 1) * sizeof(real);
     const int warm = carry && (psd_calls % PSD_WARM_RESET) != 0;
     ++psd_calls;
     if (lds > 48 * 1024)
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_psd_jacobi),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
-                       psd_work.p, psd_kmax, use_lds, status.p, psd_vprev.p, warm);
+                       psd_work.p, psd_kmax, lds_kmax, status.p, psd_vprev.p, warm);
   }
   proj_exp_pow(cw);
 }
