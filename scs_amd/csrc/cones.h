@@ -8,7 +8,13 @@ namespace scsamd {
 
 typedef scs_float real;
 
+struct BigPsd; // psd_big.h
+
 struct ConeDev {
+  ~ConeDev();
+  ConeDev() = default;
+  ConeDev(const ConeDev &) = delete;
+  ConeDev &operator=(const ConeDev &) = delete;
   int m = 0;
   hipStream_t stream = nullptr;
   // layout (row offsets into the length-m cone vector)
@@ -29,10 +35,11 @@ struct ConeDev {
   // PSD cones
   int n_psd = 0, psd_kmax = 0, psd_lds_kmax = 0;
   DevBuf<int> psd_off, psd_k;
-  DevBuf<real> psd_work;    // global scratch for blocks that do not fit in LDS
+  DevBuf<real> psd_work;    // unused (kept for the kernel signature)
+  BigPsd *psd_big = nullptr; // blocks of order > PSD_LDS_KMAX: chip-wide Jacobi steps
   DevBuf<real> psd_vprev;   // per block: eigenbasis of the previous projection (warm start; k <= 72)
   long long psd_calls = 0;  // projections since the last cold start
-  void reset_warm_start() { psd_calls = 0; }
+  void reset_warm_start();
   // exponential (primal, dual) and power cones: 3 rows each, after the PSD blocks
   int ep = 0, ed = 0, psize = 0, exp_off = 0;
   DevBuf<real> pow_a;       // psize power-cone parameters (negative = dual cone)

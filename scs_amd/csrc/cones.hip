@@ -369,6 +369,33 @@ __device__ __forceinline__ void psd_lds_matmul(real *C, const real *L, const rea
 #endif
 }
 
+// entry (i, j) of the full symmetric matrix behind a packed block, diagonal * sqrt(2) (cones.c:1018-1025); for a
+// complex Hermitian block of order nn (k = 2 nn) the entry of its real symmetric embedding [[A, -B], [B, A]]
+__device__ __forceinline__ real psd_unpack_entry(const real *X, int k, bool cplx, int nn, int i, int j) {
+  const real sqrt2 = sqrt((real)2);
+  real v = 0;
+  if (i < k && j < k) {
+    if (!cplx) {
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      v = X[packed_index(hi, lo, k)];
+      if (i == j) v *= sqrt2;
+    } else {
+      // column c of the packed Hermitian lower triangle starts at c (2 nn - c): real diagonal,
+      // then (re, im) pairs of rows c+1.. (cones.c:1095-1103)
+      const int bi = i / nn, bj = j / nn, ii = i % nn, jj = j % nn;
+      const int r = ii > jj ? ii : jj, c = ii > jj ? jj : ii;
+      if (bi == bj) { // A block: real part, symmetric
+        v = r == c ? X[c * (2 * nn - c)] * sqrt2 : X[c * (2 * nn - c) + 1 + 2 * (r - c - 1)];
+      } else if (r != c) { // +-B block: imaginary part, antisymmetric
+        real im = X[c * (2 * nn - c) + 2 + 2 * (r - c - 1)]; // Im H[r][c], r > c
+        if (ii < jj) im = -im;                                // B[ii][jj] = -B[jj][ii]
+        v = (bi == 1 && bj == 0) ? im : -im;                  // M[i+nn][j] = B, M[i][j+nn] = -B
+      }
+    }
+  }
+  return v;
+}
+
 // vprev (nullable): per cone a K2m x ldm eigenbasis carried from the previous projection.  With
 // warm != 0 the iteration starts from A' = Vp' A Vp (nearly diagonal when consecutive ADMM
 // iterates are close) and V = Vp, so it needs 1-2 sweeps instead of ~8; the basis is written back
@@ -408,6 +435,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   const int ld = K2 | 1; // odd leading dimension: conflict-free row and column walks
   const int K2m = (kmax + 1) & ~1, ldm = K2m | 1;
   const bool use_lds = k <= lds_kmax; // per block: small blocks stay in LDS next to a large one in the same program
+  if (!use_lds) return; // larger blocks: psd_big.h (chip-wide steps)
   real *A = use_lds ? lds_mat : scratch + (size_t)cone * 2 * K2m * ldm;
   real *V = A + (size_t)K2 * ld;
   // element (r, c): in LDS row-major with an odd leading dimension (lanes that walk rows hit distinct banks); in the
@@ -418,26 +446,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   // unpack: full symmetric, diagonal * sqrt(2)  (cones.c:1018-1025)
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
     const int i = e % K2, j = e / K2;
-    real v = 0;
-    if (i < k && j < k) {
-      if (!cplx) {
-        const int hi = i > j ? i : j, lo = i > j ? j : i;
-        v = X[packed_index(hi, lo, k)];
-        if (i == j) v *= sqrt2;
-      } else {
-        // column c of the packed Hermitian lower triangle starts at c (2 nn - c): real diagonal,
-        // then (re, im) pairs of rows c+1.. (cones.c:1095-1103)
-        const int bi = i / nn, bj = j / nn, ii = i % nn, jj = j % nn;
-        const int r = ii > jj ? ii : jj, c = ii > jj ? jj : ii;
-        if (bi == bj) { // A block: real part, symmetric
-          v = r == c ? X[c * (2 * nn - c)] * sqrt2 : X[c * (2 * nn - c) + 1 + 2 * (r - c - 1)];
-        } else if (r != c) { // +-B block: imaginary part, antisymmetric
-          real im = X[c * (2 * nn - c) + 2 + 2 * (r - c - 1)]; // Im H[r][c], r > c
-          if (ii < jj) im = -im;                                // B[ii][jj] = -B[jj][ii]
-          v = (bi == 1 && bj == 0) ? im : -im;                  // M[i+nn][j] = B, M[i][j+nn] = -B
-        }
-      }
-    }
+    const real v = psd_unpack_entry(X, k, cplx, nn, i, j);
     A[MI(i, j)] = v;
     V[MI(i, j)] = i == j ? (real)1 : (real)0;
   }
@@ -636,6 +645,16 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
 #endif
 }
 
+} // namespace scsamd
+#include "psd_big.h"
+namespace scsamd {
+
+ConeDev::~ConeDev() { delete psd_big; }
+void ConeDev::reset_warm_start() {
+  psd_calls = 0;
+  if (psd_big) psd_big->reset_warm_start();
+}
+
 // ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
@@ -675,7 +694,6 @@ int validate_cone(const ScsCone *k, int m, bool verbose) {
   if (k->ssize < 0 || (k->ssize > 0 && !k->s)) CONE_FAIL("sd cone dimension error");
   for (int i = 0; i < k->ssize; ++i) {
     if (k->s[i] < 0) CONE_FAIL("sd cone dimension error");
-    if (k->s[i] > PSD_K_LIMIT) CONE_FAIL("sd cone larger than 1024 x 1024 not supported by the MI355X backend");
   }
   if (k->cssize < 0 || (k->cssize > 0 && !k->cs)) CONE_FAIL("complex psd cone dimension error");
   for (int i = 0; i < k->cssize; ++i) {
@@ -806,8 +824,12 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
     const int ka = kk < 0 ? -kk : kk;
     if (ka <= PSD_LDS_KMAX) psd_lds_kmax = std::max(psd_lds_kmax, ka);
   }
-  if (n_psd && psd_kmax > PSD_LDS_KMAX)
-    psd_work.alloc((size_t)n_psd * 2 * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
+  delete psd_big;
+  psd_big = nullptr;
+  if (n_psd && psd_kmax > PSD_LDS_KMAX) { // blocks that do not fit one CU's LDS: chip-wide Jacobi steps (psd_big.h)
+    psd_big = new BigPsd;
+    psd_big->init(pk, PSD_LDS_KMAX, stream);
+  }
   psd_calls = 0;
   if (n_psd && psd_kmax <= PSD_WARM_KMAX && !getenv("SCS_AMD_PSD_COLD"))
     psd_vprev.alloc((size_t)n_psd * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
@@ -864,6 +886,7 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
                        psd_work.p, psd_kmax, lds_kmax, status.p, psd_vprev.p, warm);
+    if (psd_big) psd_big->project(cw, psd_off.p, psd_k.p, status.p, stream);
   }
   proj_exp_pow(cw);
 }

@@ -1,0 +1,469 @@
+// psd_big.h -- PSD blocks whose A and V do not fit one CU's LDS (order > PSD_LDS_KMAX): the same parallel cyclic
+// Jacobi iteration as k_psd_jacobi (cones.hip), every step spread over the whole chip instead of one workgroup.
+// Replaces LAPACK dsyevr / zheevr + the reconstruction of reference src/cones.c:999-1155 for those blocks; no size
+// limit other than memory.  Included by cones.hip only (uses its RotCS, packed_index, psd_unpack_entry).
+//
+// Per big block (all in HBM, column-major, common leading dimension ld = even-padded largest order):
+//   A (K2 x K2 working matrix), V (eigenvectors), rotation tables of one step, a small control record.
+// One Jacobi step = two launches over all big blocks (blockIdx.y = block):
+//   k_bp_params  one workgroup per block: the K2/2 disjoint rotations of round-robin step `step` from the current A
+//                (same formulas, same threshold rule, same round-robin order as the LDS kernel), "does anything
+//                rotate" flag, running max of the off-diagonal entries met in this sweep
+//   k_bp_update  chip-wide: A <- J' A J as independent 2x2 blocks (one lane each) and V <- V J, lanes walking rows
+//                (consecutive addresses); returns at once for converged blocks / steps without rotation
+// k_bp_sweep_end closes a sweep (convergence, sweep cap as in cones.c:1031), the host reads one int per sweep.
+// Reconstruction X+ = W W' (W = V diag(sqrt(max(lambda, 0)))) runs on the fp64 matrix cores over all CUs (k_bp_gram).
+// Everything is deterministic: no atomics in sums, one workgroup owns every reduction.
+//
+// Measured (profiles/r2_bench_psd_sizes_*.jsonl): see DESIGN.md section 6.
+#pragma once
+
+namespace scsamd {
+
+struct BigPsdCtl {
+  real thr, fro, offmax;
+  int any[2];
+  int done, sweeps, kraw; // kraw: signed order (negative = complex embedding), copied here so that a step kernel
+                          // needs ONE dependent read (this record) before it touches A
+};
+
+constexpr int BP_THREADS = 256;
+constexpr int BP_PARAM_THREADS = 1024;
+
+struct BigPsdView {
+  int nbig, ld;           // blocks, common leading dimension (= K2 of the largest)
+  const int *id;          // index of each big block in psd_off / psd_k
+  const int *psd_off, *psd_k;
+  real *A, *V;            // nbig * ld * ld each
+  RotCS *rot_cs;          // nbig * ld / 2
+  int2 *rot_pq;
+  BigPsdCtl *ctl;         // nbig
+};
+
+struct BlockShape {
+  int k, K2, nn, npairs;
+  bool cplx;
+};
+__device__ __forceinline__ BlockShape bp_shape_raw(int kraw) {
+  BlockShape s;
+  s.cplx = kraw < 0;
+  s.k = s.cplx ? -kraw : kraw;
+  s.nn = s.k / 2;
+  s.K2 = (s.k + 1) & ~1;
+  s.npairs = s.K2 / 2;
+  return s;
+}
+__device__ __forceinline__ BlockShape bp_shape(const BigPsdView &B, int b) { return bp_shape_raw(B.psd_k[B.id[b]]); }
+
+// A <- unpacked block (diagonal * sqrt 2), V <- I
+__global__ __launch_bounds__(BP_THREADS) void k_bp_unpack(BigPsdView B, const real *__restrict__ x, int set_identity) {
+  const int b = blockIdx.y;
+  const BlockShape s = bp_shape(B, b);
+  const real *X = x + B.psd_off[B.id[b]];
+  real *A = B.A + (size_t)b * B.ld * B.ld, *V = B.V + (size_t)b * B.ld * B.ld;
+  const long long total = (long long)s.K2 * s.K2;
+  for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * BP_THREADS) {
+    const int i = (int)(e % s.K2), j = (int)(e / s.K2);
+    A[(size_t)j * B.ld + i] = psd_unpack_entry(X, s.k, s.cplx, s.nn, i, j);
+    if (set_identity) V[(size_t)j * B.ld + i] = i == j ? (real)1 : (real)0;
+  }
+}
+
+// Frobenius norm (fixed summation order: one workgroup per block), threshold, control record armed
+__global__ __launch_bounds__(BP_PARAM_THREADS) void k_bp_norm(BigPsdView B) {
+  __shared__ real red[BP_PARAM_THREADS / SCSAMD_WAVE];
+  const int b = blockIdx.y;
+  const BlockShape s = bp_shape(B, b);
+  const real *A = B.A + (size_t)b * B.ld * B.ld;
+  real fro = 0;
+  const long long total = (long long)s.K2 * s.K2;
+  for (long long e = threadIdx.x; e < total; e += BP_PARAM_THREADS) {
+    const real v = A[(size_t)(e / s.K2) * B.ld + (e % s.K2)];
+    fro += v * v;
+  }
+  fro = sqrt(block_sum(fro, red));
+  if (threadIdx.x == 0) {
+    const real eps = sizeof(real) == 8 ? (real)1e-15 : (real)1e-7;
+    BigPsdCtl *c = B.ctl + b;
+    c->fro = fro;
+    // same rule as k_psd_jacobi (fp32: not below the rounding noise of the rotations)
+    c->thr = sizeof(real) == 8 ? eps * fro / (real)s.k : fmaxf(eps * fro / (real)s.k, (real)2.4e-7 * fro);
+    c->offmax = 0;
+    c->any[0] = c->any[1] = 0;
+    c->done = fro > (real)0 ? 0 : 1;
+    c->sweeps = 0;
+    c->kraw = B.psd_k[B.id[b]];
+  }
+}
+
+// rotations of one round-robin step
+__global__ __launch_bounds__(BP_PARAM_THREADS) void k_bp_params(BigPsdView B, int step) {
+  __shared__ real red[BP_PARAM_THREADS / SCSAMD_WAVE];
+  const int b = blockIdx.y;
+  BigPsdCtl *ctl = B.ctl + b;
+  if (ctl->done) return;
+  const BlockShape sh = bp_shape_raw(ctl->kraw);
+  if (step >= sh.K2 - 1) return; // smaller block than the largest: its sweep has fewer steps
+  const real *A = B.A + (size_t)b * B.ld * B.ld;
+  RotCS *rot_cs = B.rot_cs + (size_t)b * (B.ld / 2);
+  int2 *rot_pq = B.rot_pq + (size_t)b * (B.ld / 2);
+  const real thr = ctl->thr;
+  const int K2 = sh.K2, k = sh.k, ld = B.ld;
+  real offmax = 0;
+  int any = 0;
+  for (int i = threadIdx.x; i < sh.npairs; i += BP_PARAM_THREADS) {
+    int p = i == 0 ? 0 : 1 + ((i - 1 + step) % (K2 - 1));
+    int q = 1 + ((K2 - 2 - i + step) % (K2 - 1));
+    if (p > q) {
+      const int t = p;
+      p = q;
+      q = t;
+    }
+    real c = 1, s = 0;
+    const real apq = A[(size_t)q * ld + p];
+    const real aa = absval(apq);
+    if (q < k) offmax = aa > offmax ? aa : offmax;
+    if (q < k && aa > thr) {
+      const real d = A[(size_t)q * ld + q] - A[(size_t)p * ld + p], bb = (real)2 * apq;
+      const real h = sqrt(d * d + bb * bb);
+      const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
+      c = rsqrt(t * t + (real)1);
+      s = t * c;
+      any = 1;
+    }
+    rot_pq[i] = make_int2(p, q);
+    rot_cs[i] = RotCS{c, s};
+  }
+  any = __syncthreads_or(any);
+  offmax = block_max(offmax, red);
+  if (threadIdx.x == 0) {
+    ctl->any[step & 1] = any;
+    if (offmax > ctl->offmax) ctl->offmax = offmax;
+  }
+}
+
+__global__ __launch_bounds__(BP_THREADS) void k_bp_update(BigPsdView B, int step) {
+  const int b = blockIdx.y;
+  const BigPsdCtl *ctl = B.ctl + b;
+  if (ctl->done || !ctl->any[step & 1]) return;
+  const BlockShape sh = bp_shape_raw(ctl->kraw);
+  if (step >= sh.K2 - 1) return;
+  real *A = B.A + (size_t)b * B.ld * B.ld, *V = B.V + (size_t)b * B.ld * B.ld;
+  const RotCS *rot_cs = B.rot_cs + (size_t)b * (B.ld / 2);
+  const int2 *rot_pq = B.rot_pq + (size_t)b * (B.ld / 2);
+  const int npairs = sh.npairs, K2 = sh.K2;
+  const size_t ld = B.ld;
+  const long long nblk = (long long)npairs * npairs, nv = (long long)K2 * npairs;
+  for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < nblk + nv; e += (long long)gridDim.x * BP_THREADS) {
+    if (e < nblk) {
+      // consecutive lanes walk the ROW pairs: consecutive p1 (and q1) -> consecutive addresses in column-major storage
+      const int Q = (int)(e / npairs), P = (int)(e % npairs);
+      const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
+      const RotCS r1 = rot_cs[P], r2 = rot_cs[Q];
+      const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
+      const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
+      const size_t i11 = p2 * ld + p1, i12 = q2 * ld + p1, i21 = p2 * ld + q1, i22 = q2 * ld + q1;
+      const real a11 = A[i11], a12 = A[i12], a21 = A[i21], a22 = A[i22];
+      const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
+      const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
+      const bool own = P == Q && s1 != (real)0; // the rotated pair's own off-diagonal entry: exact zero
+      A[i11] = c2 * r11 - s2 * r12;
+      A[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
+      A[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
+      A[i22] = s2 * r21 + c2 * r22;
+    } else {
+      const long long f = e - nblk;
+      const int Q = (int)(f / K2), i = (int)(f % K2);
+      const int2 pq2 = rot_pq[Q];
+      const RotCS r2 = rot_cs[Q];
+      const size_t ip = pq2.x * ld + i, iq = pq2.y * ld + i;
+      const real vp = V[ip], vq = V[iq];
+      V[ip] = r2.c * vp - r2.s * vq;
+      V[iq] = r2.s * vp + r2.c * vq;
+    }
+  }
+}
+
+// closes a sweep for every block; *remaining = blocks still iterating
+__global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int rem = 0;
+  for (int b = 0; b < B.nbig; ++b) {
+    BigPsdCtl *c = B.ctl + b;
+    if (c->done) continue;
+    c->sweeps += 1;
+    if (c->offmax <= c->thr) {
+      c->done = 1;
+    } else if (c->sweeps >= PSD_MAX_SWEEPS) {
+      c->done = 1;
+      atomicAdd(status, 1); // did not converge: counted, not fatal (cones.c:1031-1032)
+    } else {
+      ++rem;
+    }
+    c->offmax = 0;
+  }
+  *remaining = rem;
+}
+
+// W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044), in place
+__global__ __launch_bounds__(BP_THREADS) void k_bp_scale(BigPsdView B) {
+  const int b = blockIdx.y;
+  const BlockShape s = bp_shape(B, b);
+  const real *A = B.A + (size_t)b * B.ld * B.ld;
+  real *V = B.V + (size_t)b * B.ld * B.ld;
+  const long long total = (long long)s.K2 * s.K2;
+  for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * BP_THREADS) {
+    const int i = (int)(e % s.K2), c = (int)(e / s.K2);
+    const real lam = A[(size_t)c * B.ld + c];
+    V[(size_t)c * B.ld + i] *= (c < s.k && lam > (real)0) ? sqrt(lam) : (real)0;
+  }
+}
+
+// X+ = W W', packed lower triangle with diagonal / sqrt(2) (cones.c:1052-1063): real blocks on the fp64 matrix cores,
+// one 16x16 output tile per wave (lane l supplies W[row l&15][k l>>4] for both operands; D element (row (l>>4) + 4 reg,
+// col l&15)).  Complex blocks and the fp32 build: one lane per packed output entry.
+__global__ __launch_bounds__(BP_THREADS) void k_bp_gram(BigPsdView B, real *x) {
+  const int b = blockIdx.y;
+  const BlockShape s = bp_shape(B, b);
+  real *X = x + B.psd_off[B.id[b]];
+  const real *W = B.V + (size_t)b * B.ld * B.ld;
+  const size_t ld = B.ld;
+  const real inv_sqrt2 = (real)1 / sqrt((real)2);
+  const int k = s.k;
+  if (s.cplx) { // Hermitian repack (cones.c:1139-1145): Re = (W W')[r][c], Im = (W W')[r+nn][c]
+    const int nn = s.nn;
+    for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < (long long)nn * nn; e += (long long)gridDim.x * BP_THREADS) {
+      int c = 0;
+      long long rem = e;
+      while (rem >= 2 * (nn - c) - 1) {
+        rem -= 2 * (nn - c) - 1;
+        ++c;
+      }
+      int ra, rb = c;
+      real scale = 1;
+      if (rem == 0) {
+        ra = c;
+        scale = inv_sqrt2;
+      } else {
+        const int r = c + 1 + (int)((rem - 1) / 2);
+        ra = ((rem - 1) & 1) ? r + nn : r;
+      }
+      real acc = 0;
+      for (int cc = 0; cc < k; ++cc) acc += W[cc * ld + ra] * W[cc * ld + rb];
+      X[e] = acc * scale;
+    }
+    return;
+  }
+#ifndef SFLOAT
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = BP_THREADS >> 6;
+  const int T = (k + 15) >> 4;
+  const long long ntile = (long long)T * (T + 1) / 2;
+  const int ksteps = (s.K2 + 3) >> 2;
+  const int li = lane & 15, lk = lane >> 4;
+  for (long long t = (long long)blockIdx.x * nw + wave; t < ntile; t += (long long)gridDim.x * nw) {
+    // t -> (ti, tj), tj <= ti, rows of tiles enumerated one after the other
+    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long long)ti * (ti + 1) / 2 > t) --ti;
+    while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = (int)(t - (long long)ti * (ti + 1) / 2);
+    f64x4 acc = {0, 0, 0, 0};
+    const int ra = ti * 16 + li, rb = tj * 16 + li;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int kc = ks * 4 + lk;
+      const double av = (ra < k && kc < s.K2) ? W[kc * ld + ra] : 0.0;
+      const double bv = (rb < k && kc < s.K2) ? W[kc * ld + rb] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
+      if (i < k && j <= i) X[packed_index(i, j, k)] = i == j ? acc[r] * inv_sqrt2 : acc[r];
+    }
+  }
+#else
+  const long long ntri = (long long)k * (k + 1) / 2;
+  for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < ntri; e += (long long)gridDim.x * BP_THREADS) {
+    int j = 0;
+    long long rem = e;
+    while (rem >= k - j) {
+      rem -= k - j;
+      ++j;
+    }
+    const int i = j + (int)rem;
+    real acc = 0;
+    for (int cc = 0; cc < k; ++cc) acc += W[cc * ld + i] * W[cc * ld + j];
+    if (i == j) acc *= inv_sqrt2;
+    X[e] = acc;
+  }
+#endif
+}
+
+__global__ void k_bp_set_kraw(BigPsdView B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B.nbig) B.ctl[b].kraw = B.psd_k[B.id[b]];
+}
+
+// C = L' R for K2 x K2 column-major matrices (both operands contiguous along the summation index): the two products
+// of the warm start A' = Vp' (A Vp) -- A is symmetric, so A Vp = A' Vp.  fp64 matrix cores, one 16x16 tile of C per wave;
+// lane (li = l & 15, lk = l >> 4) owns the summation indices 16 kk + 4 lk + s for MFMA step s of chunk kk (any
+// assignment works as long as both operands use the same one), i.e. one 32-byte run per operand and chunk, so a wave
+// reads whole 128-byte lines.  fp32 build: plain loops.
+__global__ __launch_bounds__(BP_THREADS) void k_bp_gemm_tn(BigPsdView B, real *C, const real *__restrict__ L, const real *__restrict__ R) {
+  const int b = blockIdx.y;
+  const BlockShape s = bp_shape_raw(B.ctl[b].kraw);
+  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
+  const int K2 = s.K2;
+  C += mat;
+  L += mat;
+  R += mat;
+#ifndef SFLOAT
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = BP_THREADS >> 6;
+  const int T = (K2 + 15) >> 4, li = lane & 15, lk = lane >> 4;
+  const int chunks = (K2 + 15) >> 4;
+  for (long long t = (long long)blockIdx.x * nw + wave; t < (long long)T * T; t += (long long)gridDim.x * nw) {
+    const int ti = (int)(t % T), tj = (int)(t / T);
+    const int ra = ti * 16 + li, cb = tj * 16 + li;
+    f64x4 acc = {0, 0, 0, 0};
+    for (int kk = 0; kk < chunks; ++kk) {
+      const int k0 = kk * 16 + lk * 4;
+      double a[4], bb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = k0 + q < K2;
+        a[q] = (ok && ra < K2) ? L[ra * ld + k0 + q] : 0.0;
+        bb[q] = (ok && cb < K2) ? R[cb * ld + k0 + q] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bb[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
+      if (i < K2 && j < K2) C[j * ld + i] = acc[r];
+    }
+  }
+#else
+  for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < (long long)K2 * K2; e += (long long)gridDim.x * BP_THREADS) {
+    const int i = (int)(e % K2), j = (int)(e / K2);
+    real acc = 0;
+    for (int kc = 0; kc < K2; ++kc) acc += L[i * ld + kc] * R[j * ld + kc];
+    C[j * ld + i] = acc;
+  }
+#endif
+}
+
+// A <- (A + A') / 2 (the rotations assume exact symmetry)
+__global__ __launch_bounds__(BP_THREADS) void k_bp_symm(BigPsdView B) {
+  const int b = blockIdx.y;
+  const BlockShape s = bp_shape_raw(B.ctl[b].kraw);
+  real *A = B.A + (size_t)b * B.ld * B.ld;
+  const size_t ld = B.ld;
+  for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < (long long)s.K2 * s.K2; e += (long long)gridDim.x * BP_THREADS) {
+    const int i = (int)(e % s.K2), j = (int)(e / s.K2);
+    if (i > j) {
+      const real v = (real)0.5 * (A[j * ld + i] + A[i * ld + j]);
+      A[j * ld + i] = v;
+      A[i * ld + j] = v;
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+struct BigPsd {
+  int nbig = 0, kmax = 0, ld = 0;
+  DevBuf<int> id;
+  DevBuf<real> A, V, Vp, Tm; // working matrix, eigenvectors / W, carried eigenbasis, warm-start temporary
+  bool have_basis = false;
+  long long calls = 0;
+  DevBuf<RotCS> rot_cs;
+  DevBuf<int2> rot_pq;
+  DevBuf<BigPsdCtl> ctl;
+  DevBuf<int> remaining;
+  long long sweeps_total = 0, projections = 0;
+  bool warm_ok = true;
+  void reset_warm_start() { calls = 0; have_basis = false; }
+
+  // pk: signed orders of all PSD blocks (negative = complex embedding order); blocks above lds_kmax are taken
+  void init(const std::vector<int> &pk, int lds_kmax, hipStream_t st) {
+    std::vector<int> ids;
+    kmax = 0;
+    for (size_t i = 0; i < pk.size(); ++i) {
+      const int ka = pk[i] < 0 ? -pk[i] : pk[i];
+      if (ka > lds_kmax) {
+        ids.push_back((int)i);
+        kmax = std::max(kmax, ka);
+      }
+    }
+    nbig = (int)ids.size();
+    if (!nbig) return;
+    ld = (kmax + 1) & ~1;
+    id.alloc(ids.size());
+    id.upload(ids.data(), ids.size(), st);
+    A.alloc((size_t)nbig * ld * ld);
+    V.alloc((size_t)nbig * ld * ld);
+    warm_ok = !getenv("SCS_AMD_PSD_COLD");
+    if (warm_ok) {
+      Vp.alloc((size_t)nbig * ld * ld);
+      Tm.alloc((size_t)nbig * ld * ld);
+    }
+    have_basis = false;
+    calls = 0;
+    rot_cs.alloc((size_t)nbig * (ld / 2));
+    rot_pq.alloc((size_t)nbig * (ld / 2));
+    ctl.alloc(nbig);
+    remaining.alloc(1);
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+
+  // x: the cone vector (device); status: the ConeDev sweep-cap counter
+  void project(real *x, const int *psd_off, const int *psd_k, int *status, hipStream_t st) {
+    if (!nbig) return;
+    BigPsdView B{nbig, ld, id.p, psd_off, psd_k, A.p, V.p, rot_cs.p, rot_pq.p, ctl.p};
+    const long long elems = (long long)ld * ld;
+    const int g_elem = (int)std::min<long long>((elems + BP_THREADS - 1) / BP_THREADS, 2048);
+    const long long items = (long long)(ld / 2) * (ld / 2) + (long long)ld * (ld / 2);
+    const int g_upd = (int)std::min<long long>((items + BP_THREADS - 1) / BP_THREADS, 4096);
+    // warm start (as in the LDS kernel): iterate on A' = Vp' A Vp from V = Vp, the eigenbasis of the previous projection
+    // of the same block; a cold restart every PSD_WARM_RESET calls bounds the orthogonality drift of the carried basis
+    const bool warm = warm_ok && have_basis && (calls % PSD_WARM_RESET) != 0;
+    ++calls;
+    const size_t mat_bytes = (size_t)nbig * ld * ld * sizeof(real);
+    hipLaunchKernelGGL(k_bp_set_kraw, dim3((nbig + 63) / 64), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(k_bp_unpack, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B, x, warm ? 0 : 1);
+    if (warm) {
+      const long long T16 = (ld + 15) / 16;
+      const int g_mm = (int)std::min<long long>((T16 * T16 + 3) / 4, 8192);
+      HIP_CHECK(hipMemcpyAsync(V.p, Vp.p, mat_bytes, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_bp_gemm_tn, dim3(g_mm, nbig), dim3(BP_THREADS), 0, st, B, Tm.p, (const real *)A.p, (const real *)V.p); // T = A' Vp = A Vp
+      hipLaunchKernelGGL(k_bp_gemm_tn, dim3(g_mm, nbig), dim3(BP_THREADS), 0, st, B, A.p, (const real *)V.p, (const real *)Tm.p); // A = Vp' T
+      hipLaunchKernelGGL(k_bp_symm, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B);
+    }
+    hipLaunchKernelGGL(k_bp_norm, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B);
+    int h_rem = nbig;
+    const long long sweeps_before = sweeps_total;
+    for (int sweep = 0; sweep < PSD_MAX_SWEEPS && h_rem > 0; ++sweep) {
+      for (int step = 0; step < ld - 1; ++step) {
+        hipLaunchKernelGGL(k_bp_params, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B, step);
+        hipLaunchKernelGGL(k_bp_update, dim3(g_upd, nbig), dim3(BP_THREADS), 0, st, B, step);
+      }
+      hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p);
+      HIP_CHECK(hipMemcpyAsync(&h_rem, remaining.p, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      ++sweeps_total;
+    }
+    ++projections;
+    static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "[scs_amd psd_big] projection %lld: %s start, sweeps so far %lld (this one %lld)\n", projections, warm ? "warm" : "cold", sweeps_total, sweeps_total - sweeps_before);
+    if (warm_ok) {
+      HIP_CHECK(hipMemcpyAsync(Vp.p, V.p, mat_bytes, hipMemcpyDeviceToDevice, st));
+      have_basis = true;
+    }
+    hipLaunchKernelGGL(k_bp_scale, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B);
+    const long long T = (kmax + 15) / 16, ntile = T * (T + 1) / 2;
+    const long long outs = (long long)kmax * (kmax + 1) / 2;
+    const int g_gram = (int)std::min<long long>(std::max<long long>((ntile + 3) / 4, (outs + 64LL * BP_THREADS - 1) / (64LL * BP_THREADS)), 8192);
+    hipLaunchKernelGGL(k_bp_gram, dim3(std::max(1, g_gram), nbig), dim3(BP_THREADS), 0, st, B, x);
+  }
+};
+
+} // namespace scsamd

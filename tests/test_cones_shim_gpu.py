@@ -160,3 +160,30 @@ def test_large_box_cone_multi_workgroup_path_matches_reference(nb, monkeypatch):
     for use_scal in (True, False):
         for a, b in zip(outs[(use_scal, "1")], outs[(use_scal, "0")]):
             assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("cone", [dict(s=[100, 10, 131]), dict(s=[200], cs=[60]), dict(s=[300])])
+def test_psd_blocks_beyond_the_lds_path_match_reference(cone):
+    """Blocks of order > 92 (A and V no longer fit one CU's LDS) run the Jacobi steps as chip-wide launches
+    (psd_big.h), next to small blocks that stay in LDS; complex Hermitian blocks through their real embedding
+    (order 2 * 60 = 120).  Same projection as the reference's LAPACK path (src/cones.c:999-1155) to 1e-11, twice
+    (the second call reuses the device workspace)."""
+    ref = _ref_lib()
+    lib = _lib()
+    Tr = ref._scs_types
+    m = capi.cone_rows(cone)
+    kr = capi.make_cone(cone, Tr)
+    wr = ref._scs_init_cone(C.byref(kr), m)
+    k = capi.make_cone(cone)
+    c = lib._scs_init_cone(C.byref(k), m)
+    assert c and wr
+    for rep in range(2):
+        x0 = np.random.default_rng(7 + rep).standard_normal(m)
+        got, want = x0.copy(), x0.copy()
+        assert lib._scs_proj_dual_cone(got.ctypes.data_as(T.fp), c, None, None) == 0
+        assert ref._scs_proj_dual_cone(want.ctypes.data_as(Tr.fp), wr, None, None) == 0
+        err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        assert err <= 1e-11, (cone, rep, err)
+        assert np.abs(got - x0).max() > 1e-3
+    lib._scs_finish_cone(c)
+    ref._scs_finish_cone(wr)
