@@ -155,13 +155,46 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, re
                                                             real *part_ztr, real *part_max,
                                                             const CgCtl *ctl, int parity) {
   __shared__ real red[4];
-  if (ctl->cg_done) return;
-  const real pgp = reduce_partials_sum(part_pgp, cnt_pgp, red);
-  const real alpha = ctl->ztr[parity] / pgp;
-  real ztr = 0, mx = 0;
+  // small systems are bound by chains of dependent reads (~1 us each: the operands were written by the previous
+  // kernel on other CUs): the lane's first vector chunk, the control words and the partials are all requested
+  // before anything is waited for -- one round trip instead of four
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
   const int nv = n / RVW;
-  for (int iv = gtid; iv < nv; iv += gs) { // 16 B per lane per array
+  const bool has = gtid < nv;
+  rvec P0 = {}, G0 = {}, M0 = {}, X0 = {}, R0 = {};
+  if (has) {
+    P0 = ldv(p, gtid);
+    G0 = ldv(Gp, gtid);
+    M0 = ldv(M, gtid);
+    X0 = ldv(x, gtid);
+    R0 = ldv(r, gtid);
+  }
+  const int done = ctl->cg_done;
+  const real ztr_in = ctl->ztr[parity];
+  real psum = 0;
+  for (int i = threadIdx.x; i < cnt_pgp; i += blockDim.x) psum += part_pgp[i];
+  if (done) return;
+  const real pgp = block_sum(psum, red); // = reduce_partials_sum(part_pgp, cnt_pgp, red)
+  const real alpha = ztr_in / pgp;
+  real ztr = 0, mx = 0;
+  if (has) {
+    rvec Z;
+#pragma unroll
+    for (int e = 0; e < RVW; ++e) {
+      X0.v[e] += alpha * P0.v[e];
+      const real ri = R0.v[e] + (-alpha) * G0.v[e];
+      R0.v[e] = ri;
+      const real zi = ri * M0.v[e];
+      Z.v[e] = zi;
+      ztr += zi * ri;
+      const real a = absval(ri);
+      mx = a > mx ? a : mx;
+    }
+    stv(x, gtid, X0);
+    stv(r, gtid, R0);
+    stv(z, gtid, Z);
+  }
+  for (int iv = gtid + gs; iv < nv; iv += gs) { // 16 B per lane per array
     const rvec P = ldv(p, iv), G = ldv(Gp, iv), Mv = ldv(M, iv);
     rvec X = ldv(x, iv), R = ldv(r, iv), Z;
 #pragma unroll
@@ -204,17 +237,36 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const re
                                                                const real *part_max, int pcount,
                                                                CgCtl *ctl, int parity) {
   __shared__ real red[4];
-  if (ctl->cg_done) return;
-  const real ztr = reduce_partials_sum(part_ztr, pcount, red);
-  const real nr = reduce_partials_max(part_max, pcount, red);
-  const real ztr_prev = ctl->ztr[parity];
-  const bool conv = nr < ctl->tol;
+  // as in k_cg_update: everything this kernel reads is requested up front (one round trip, not four)
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+  const int nv = n / RVW;
+  const bool has = gtid < nv;
+  rvec Z0 = {}, P0 = {};
+  if (has) {
+    Z0 = ldv(z, gtid);
+    P0 = ldv(p, gtid);
+  }
+  const int done = ctl->cg_done;
+  const real ztr_prev = ctl->ztr[parity], tol = ctl->tol;
+  real zs = 0, ms = 0;
+  for (int i = threadIdx.x; i < pcount; i += blockDim.x) {
+    zs += part_ztr[i];
+    const real v = part_max[i];
+    ms = v > ms ? v : ms;
+  }
+  if (done) return;
+  const real ztr = block_sum(zs, red); // = reduce_partials_sum(part_ztr, pcount, red)
+  const real nr = block_max(ms, red);  // = reduce_partials_max(part_max, pcount, red)
+  const bool conv = nr < tol;
   const bool brk = !conv && ztr_prev == (real)0;
   if (!conv && !brk) {
     const real beta = ztr / ztr_prev;
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
-    const int nv = n / RVW;
-    for (int iv = gtid; iv < nv; iv += gs) {
+    if (has) {
+#pragma unroll
+      for (int e = 0; e < RVW; ++e) P0.v[e] = Z0.v[e] + beta * P0.v[e];
+      stv(p, gtid, P0);
+    }
+    for (int iv = gtid + gs; iv < nv; iv += gs) {
       const rvec Z = ldv(z, iv);
       rvec P = ldv(p, iv);
 #pragma unroll
