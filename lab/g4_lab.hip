@@ -67,9 +67,11 @@ static void freeg4(G4 &A) { CK(hipFree((void *)A.ubeg)); CK(hipFree((void *)A.ue
 // with the position in the unit) -- results are wrong by construction, only the time means something
 __device__ __forceinline__ void step_body(const G4 &A, const double *__restrict__ x, double *acc, int e0, int t, int lane, unsigned cmask, int MODE, int NT, int s = 0) {
   const int e = e0 + lane * 4;
-  const int el = MODE == 4 ? s + ((e - s) & 511) : e;
+  const int el = (MODE == 4 || MODE == 5) ? s + ((e - s) & 511) : e;
   uint4 w; double2 va, vb;
-  if (NT) {
+  if (MODE == 6) {
+    w = uint4{(unsigned)e * 2654435761u, (unsigned)(e + 1) * 2654435761u, (unsigned)(e + 2) * 2654435761u, (unsigned)(e + 3) * 2654435761u}; va = double2{1.0, 1.0}; vb = double2{1.0, 1.0};
+  } else if (NT) {
     const unsigned *pw = A.w + e; const double *pv = A.val + e;
     w.x = __builtin_nontemporal_load(pw); w.y = __builtin_nontemporal_load(pw + 1); w.z = __builtin_nontemporal_load(pw + 2); w.w = __builtin_nontemporal_load(pw + 3);
     va.x = __builtin_nontemporal_load(pv); va.y = __builtin_nontemporal_load(pv + 1); vb.x = __builtin_nontemporal_load(pv + 2); vb.y = __builtin_nontemporal_load(pv + 3);
@@ -77,16 +79,16 @@ __device__ __forceinline__ void step_body(const G4 &A, const double *__restrict_
     w = *reinterpret_cast<const uint4 *>(A.w + el); va = *reinterpret_cast<const double2 *>(A.val + el); vb = *reinterpret_cast<const double2 *>(A.val + el + 2);
   }
   unsigned ww[4] = {w.x, w.y, w.z, w.w}; const double vv[4] = {va.x, va.y, vb.x, vb.y};
-  if (MODE == 4) {
+  if (MODE == 4 || MODE == 6) {
     const unsigned base = (unsigned)(((long long)(e - s) * A.cols) / max(1, t - s));
 #pragma unroll
     for (int i = 0; i < 4; ++i) { unsigned h = (unsigned)(e + i) * 2654435761u; h ^= h >> 15; ww[i] = (ww[i] & ~cmask) | min((unsigned)A.cols - 1, base + (h & 0x3fff)); }
   }
   double xx[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xx[i] = (MODE == 1) ? x[ww[i] & 63] : (e + i < t ? x[ww[i] & cmask] : 0.0);
+  for (int i = 0; i < 4; ++i) xx[i] = (MODE == 1 || MODE == 5) ? x[ww[i] & 63] : (e + i < t ? x[ww[i] & cmask] : 0.0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) if (e + i < t) __hip_atomic_fetch_add(acc + (ww[i] >> A.CB), vv[i] * xx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int i = 0; i < 4; ++i) if (e + i < t) __hip_atomic_fetch_add(acc + ((ww[i] >> A.CB) % (unsigned)A.RW), vv[i] * xx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // ---- S: wave-owned rows + scalar prefetch D steps ahead (D = 0: none).  MODE 1 = no gather.
@@ -359,6 +361,9 @@ int main(int argc, char **argv) {
     if (strchr(only, 'S')) {
       run("S D0 (no prefetch)", mk(k_g4s<4, 0, 0, 0>, A, lA), mk(k_g4s<4, 0, 0, 0>, At, lT), kV);
       run("S D0 nogather", mk(k_g4s<4, 0, 1, 0>, A, lA), mk(k_g4s<4, 0, 1, 0>, At, lT), kV);
+      run("S D0 stream from L2, no gather (MODE 5)", mk(k_g4s<4, 0, 5, 0>, A, lA), mk(k_g4s<4, 0, 5, 0>, At, lT), kV);
+      run("S D0 no stream (hashed words), real gather pattern (MODE 6)", mk(k_g4s<4, 0, 6, 0>, A, lA), mk(k_g4s<4, 0, 6, 0>, At, lT), kV);
+      if (getenv("G4_DECOMP")) { freeg4(A); freeg4(At); return 0; }
       run("P 3-stage pipeline WPB4", mk(k_g4p<4, 0>, A, lA), mk(k_g4p<4, 0>, At, lT), kV);
       run("P 3-stage pipeline WPB8", mk8(k_g4p<8, 0>, A, lA), mk8(k_g4p<8, 0>, At, lT), kV);
       run("P 3-stage pipeline WPB4 CEILING (stream from L2)", mk(k_g4p<4, 4>, A, lA), mk(k_g4p<4, 4>, At, lT), kV);

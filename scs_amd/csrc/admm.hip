@@ -763,27 +763,60 @@ static int update_scale(ScsWork *w, int iter) { // :1164-1241
   return 0;
 }
 
-// ---- printing (compact; the reference's table is src/scs.c:113-258) ---------------
+// ---- printing: the reference's layout (src/scs.c:113-272), line for line; only the banner names this backend --
+extern "C" char *_scs_get_cone_header(const ScsCone *k); // cones_shim.cpp (src/cones.c:565-581)
+static void print_rule() {
+  for (int i = 0; i < 66; ++i) putchar('-'); // LINE_LEN, scs.c:121
+  putchar('\n');
+}
 static void print_header(const ScsWork *w) {
-  printf("------------------------------------------------------------------\n");
-  printf("  scs-amd %s : ADMM hot path on MI355X (gfx950), device-resident\n", scs_version());
-  printf("  n = %d, m = %d, nnz(A) = %lld%s\n", w->n, w->m, (long long)w->A.p[w->n], w->has_P ? ", P != 0" : "");
-  printf("  cones: z %d, l %d, box %d, soc %d, psd %d, exp %d+%d, pow %d | lin-sys: %s\n", w->k.z, w->k.l, w->k.bsize,
-         w->k.qsize, w->k.ssize, w->k.ep, w->k.ed, w->k.psize, scs_get_lin_sys_method());
-  printf("  eps_abs %.1e eps_rel %.1e eps_infeas %.1e alpha %.2f scale %.2e (adaptive %d) rho_x %.2e\n",
+  print_rule();
+  printf("\t       SCS v%s - Splitting Conic Solver\n\tMI355X (gfx950) ADMM hot path, device-resident (scs_amd)\n", scs_version());
+  print_rule();
+  printf("problem:  variables n: %i, constraints m: %i\n", (int)w->n, (int)w->m);
+  if (char *cs = _scs_get_cone_header(&w->k)) {
+    printf("%s", cs);
+    free(cs);
+  } else {
+    printf("cones: <unavailable>\n");
+  }
+  printf("settings: eps_abs: %.1e, eps_rel: %.1e, eps_infeas: %.1e\n"
+         "\t  alpha: %.2f, scale: %.2e, adaptive_scale: %i\n"
+         "\t  max_iters: %i, normalize: %i, rho_x: %.2e\n",
          (double)w->stgs.eps_abs, (double)w->stgs.eps_rel, (double)w->stgs.eps_infeas, (double)w->stgs.alpha,
-         (double)w->stgs.scale, (int)w->stgs.adaptive_scale, (double)w->stgs.rho_x);
-  printf("  acceleration_lookback %d, normalize %d, max_iters %d\n", (int)w->stgs.acceleration_lookback,
-         (int)w->stgs.normalize, (int)w->stgs.max_iters);
-  printf("------------------------------------------------------------------\n");
+         (double)w->stgs.scale, (int)w->stgs.adaptive_scale, (int)w->stgs.max_iters, (int)w->stgs.normalize,
+         (double)w->stgs.rho_x);
+  if (w->stgs.acceleration_lookback != 0)
+    printf("\t  acceleration_lookback: %i, acceleration_interval: %i\n", (int)w->stgs.acceleration_lookback,
+           (int)w->stgs.acceleration_interval);
+  if (w->stgs.time_limit_secs) printf("\t  time_limit_secs: %.2e\n", (double)w->stgs.time_limit_secs);
+  printf("lin-sys:  %s\n\t  nnz(A): %li, nnz(P): %li\n", scs_get_lin_sys_method(), (long)w->A.p[w->n],
+         w->has_P ? (long)w->P.p[w->n] : 0l);
+  print_rule();
   printf(" iter | pri res | dua res |   gap   |   obj   |  scale  | time (s)\n");
-  printf("------------------------------------------------------------------\n");
+  print_rule();
 }
 static void print_summary(const ScsWork *w, int i, double t0) {
   const Resid &r = w->r_o;
-  printf("%6d| %8.2e  %8.2e  %8.2e  %9.2e  %8.2e  %8.2e\n", i, (double)r.res_pri, (double)r.res_dual,
-         (double)r.gap, (double)(0.5 * (r.pobj + r.dobj)), (double)w->stgs.scale, (now_ms() - t0) / 1e3);
+  // scs.c:207-219: total time including setup
+  printf("%*i|%*.2e %*.2e %*.2e %*.2e %*.2e %*.2e \n", 6, i, 9, (double)r.res_pri, 9, (double)r.res_dual, 9, (double)r.gap, 9,
+         (double)(0.5 * (r.pobj + r.dobj)), 9, (double)w->stgs.scale, 9, (now_ms() - t0 + w->setup_time) / 1e3);
   fflush(stdout);
+}
+static void print_footer(const ScsInfo *info) { // scs.c:246-272
+  print_rule();
+  printf("status:  %s\n", info->status);
+  printf("timings: total: %1.2es = setup: %1.2es + solve: %1.2es\n", (double)(info->setup_time + info->solve_time) / 1e3,
+         (double)info->setup_time / 1e3, (double)info->solve_time / 1e3);
+  printf("\t lin-sys: %1.2es, cones: %1.2es, accel: %1.2es\n", (double)info->lin_sys_time / 1e3,
+         (double)info->cone_time / 1e3, (double)info->accel_time / 1e3);
+  print_rule();
+  printf("objective = %.6f", (double)(0.5 * (info->pobj + info->dobj)));
+  if (info->status_val == SCS_SOLVED_INACCURATE || info->status_val == SCS_UNBOUNDED_INACCURATE ||
+      info->status_val == SCS_INFEASIBLE_INACCURATE)
+    printf(" (inaccurate)");
+  printf("\n");
+  print_rule();
 }
 
 // ---- solution extraction (:825-969) ----------------------------------------------
@@ -1340,17 +1373,7 @@ static void solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info) {
                                ? w->cone_timer.total_ms * ((double)std::max(i, 1) / (double)w->cone_timer.samples)
                                : 0.0);
   info->accel_time = (real)w->t_accel;
-  if (w->stgs.verbose) {
-    printf("------------------------------------------------------------------\n");
-    printf("status:  %s\n", info->status);
-    printf("timings: total: %.2es = setup: %.2es + solve: %.2es\n",
-           (double)(info->setup_time + info->solve_time) / 1e3, (double)info->setup_time / 1e3,
-           (double)info->solve_time / 1e3);
-    printf("\t lin-sys: %.2es, cones: %.2es, accel: %.2es\n", (double)info->lin_sys_time / 1e3,
-           (double)info->cone_time / 1e3, (double)info->accel_time / 1e3);
-    printf("objective = %.6f, iters %d, cg its %lld\n", (double)info->pobj, (int)info->iter, w->ls.tot_cg_its);
-    printf("------------------------------------------------------------------\n");
-  }
+  if (w->stgs.verbose) print_footer(info);
 }
 
 scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start) { // :1327-1484

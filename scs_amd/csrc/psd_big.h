@@ -12,6 +12,8 @@
 //   k_bp_update  chip-wide: A <- J' A J as independent 2x2 blocks (one lane each) and V <- V J, lanes walking rows
 //                (consecutive addresses); returns at once for converged blocks / steps without rotation
 // k_bp_sweep_end closes a sweep (convergence, sweep cap as in cones.c:1031), the host reads one int per sweep.
+// A step costs ~10 us whatever the order (two dependent launches, each ~3.5 us at least because it hands data to the
+// next one; replaying a sweep from a HIP graph measured no faster), so the time is steps x sweeps.
 // Reconstruction X+ = W W' (W = V diag(sqrt(max(lambda, 0)))) runs on the fp64 matrix cores over all CUs (k_bp_gram).
 // Everything is deterministic: no atomics in sums, one workgroup owns every reduction.
 //

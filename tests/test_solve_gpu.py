@@ -288,3 +288,43 @@ def test_all_cone_types_exact_cg_trajectory_equals_the_restatement(seed):
     for key in ("pobj", "dobj", "res_pri", "res_dual", "gap", "scale"):
         assert abs(ra["info"][key] - ro["info"][key]) <= 1e-6 * max(abs(ro["info"][key]), 1e-3), key
     assert np.abs(ra["x"] - ro["x"]).max() <= 1e-6 * max(1.0, np.abs(ro["x"]).max())
+
+
+def test_verbose_output_has_the_reference_layout(capfd):
+    """`verbose=1` prints the reference's tables (src/scs.c:113-272): same settings block, same column header,
+    same row and footer formats -- only the banner and the lin-sys name identify this backend."""
+    import re
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    ref = pyoracle.load_ref()
+    amd = capi.load("libscsamd.so")
+    pr = problems.random_socp(60, m=150, col_nnz=5, seed=3)
+    outs = {}
+    for name, lib in (("ref", ref), ("amd", amd)):
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=lib._scs_types)
+        capfd.readouterr()
+        capi.solve(lib, prob, verbose=1, max_iters=100, acceleration_lookback=0)
+        import ctypes as C
+        C.CDLL(None).fflush(None)
+        outs[name] = capfd.readouterr().out.splitlines()
+    r, a = outs["ref"], outs["amd"]
+    rule = "-" * 66
+    assert r.count(rule) == a.count(rule) == 7
+    for key in ("problem:  variables n:", "settings: eps_abs:", "\t  alpha:", "\t  max_iters:", " iter | pri res"):
+        lr = [l for l in r if l.startswith(key)]
+        la = [l for l in a if l.startswith(key)]
+        assert lr and lr == la, key
+    assert [l for l in a if l.startswith("lin-sys:  ")] and [l for l in a if l.startswith("\t  nnz(A): ")] == \
+        [l for l in r if l.startswith("\t  nnz(A): ")]
+    row = re.compile(r"^ *\d+\|( *-?\d\.\d\de[+-]\d\d ){6}$")
+    rows_r, rows_a = [l for l in r if row.match(l)], [l for l in a if row.match(l)]
+    assert len(rows_a) == len(rows_r) >= 2
+    assert [l.split("|")[0] for l in rows_a] == [l.split("|")[0] for l in rows_r]
+    for key, pat in (("status:  ", None), ("timings: total: ", r"^timings: total: \d\.\d\de[+-]\d\ds = setup: \d\.\d\de[+-]\d\ds \+ solve: \d\.\d\de[+-]\d\ds$"),
+                     ("\t lin-sys: ", r"^\t lin-sys: \d\.\d\de[+-]\d\ds, cones: \d\.\d\de[+-]\d\ds, accel: \d\.\d\de[+-]\d\ds$"),
+                     ("objective = ", r"^objective = -?\d+\.\d{6}( \(inaccurate\))?$")):
+        la = [l for l in a if l.startswith(key)]
+        assert len(la) == 1 and len([l for l in r if l.startswith(key)]) == 1, key
+        if pat:
+            assert re.match(pat, la[0]), la[0]
