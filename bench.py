@@ -555,6 +555,12 @@ def main():
             roof["avg_launch_us"] = avg_s * 1e6
             roof["algorithmic_bytes_per_launch"] = bytes_per_spmv
             roof["launches_timed"] = int(spmv_samples)
+            if n == 1000000 and m == 2000000 and col_nnz == 10 and args.dtype == "f64":
+                # what the same instruction stream does with the whole matrix stream served from L2 (no HBM latency in the
+                # CU's in-order memory queue): lab/g4_lab.hip ceiling test, profiles/r2_g4_lab.md section (1)/(4)
+                roof["l2_resident_ceiling_us"] = 0.5 * (57.2 + 64.3)
+                roof["launch_over_ceiling"] = roof["avg_launch_us"] / roof["l2_resident_ceiling_us"]
+                roof["ceiling_source"] = "profiles/r2_g4_lab.md (A 57.2 us, A' 64.3 us; gather-only 49/51 us, stream-only 27/26 us in the same kernel)"
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
         # only quoted for the exact workload it was measured on
         try:
