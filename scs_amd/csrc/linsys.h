@@ -30,6 +30,7 @@ struct LinSys {
   bool own_stream = false;
   bool has_P = false;
   bool use_fused = false; // whole solve in one workgroup (small systems)
+  bool use_cg2 = false;   // two launches per CG iteration (n <= CG2_N_MAX): k_cg2_a + transposed product
 
   CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector
   CsrDev A;  // CSR(A): m rows, gathers an n-vector
@@ -38,6 +39,7 @@ struct LinSys {
 
   DevBuf<real> rx, ry;               // R_x (n), R_y (m)
   DevBuf<real> M, p, r, Gp, z, Pp;   // n each
+  DevBuf<real> p2, r2;               // second direction / residual buffers of the two-launch path (p_j, r_j in {p, p2}[j & 1])
   DevBuf<real> tmp;                  // m
   DevBuf<real> partA, partB;         // reduction partials
   DevBuf<CgCtl> ctl;
@@ -52,6 +54,7 @@ struct LinSys {
   real *cg_x = nullptr; // solution vector of the current / captured solve
   bool cg_graph_tried = false, use_graph = false;
   void enqueue_cg_iteration(int q);
+  void enqueue_cg2_iteration(long long it);
   bool build_cg_graph();
   // statistics / profiling
   long long tot_cg_its = 0, n_solves = 0, n_matvecs = 0, n_spmv = 0, n_graph_launches = 0;

@@ -300,6 +300,185 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_precond(CsrView At, const real
 
 
 // ----------------------------------------------------------------------------
+// Small systems (n <= CG2_N_MAX): TWO launches per CG iteration instead of four.  Below a few thousand unknowns a CG
+// kernel costs ~3.5 us whatever it computes (it hands data to the next kernel), so the count of launches is the time.
+// k_cg2_a does, in EVERY workgroup and for ALL n entries, the update and the direction step of the previous
+// iteration (private.c:181-214; n is small, the redundant work is a few KB per workgroup, and no cross-workgroup
+// reduction is needed because every workgroup owns the complete sums), keeps the new p in LDS, and runs its share of
+// z = R_y^-1 A p gathering p from LDS; workgroup 0 alone stores x, r, p and the control words.  The transposed product
+// with the p'Gp partials stays csr_stream_kernel<EPI_GP>.  The arithmetic -- including the shape of every partial
+// sum: the virtual 256-lane workgroups of k_cg_update, their wave trees, the fixed-order re-reduction -- is exactly
+// that of the four-kernel path, so the iterates are bit-identical (tests/test_linsys_gpu.py).
+// p and r are double-buffered by iteration parity (every workgroup reads the old ones while workgroup 0 writes the new
+// ones); x is touched by workgroup 0 only.
+// ----------------------------------------------------------------------------
+constexpr int CG2_N_MAX = 1024;              // every workgroup redoes the whole update: pays off while that is ONE batch of
+                                             // loads (measured us per CG iteration, two-launch vs four-kernel: n=500 15.8,
+                                             // n=1000 16.8 vs 18.9, n=2000 19.2 vs 19.0, n=3000 23.6 vs 19.0) -- the time of
+                                             // a small CG iteration is its chain of dependent far reads (every kernel's inputs
+                                             // were just written by other CUs), however they are packaged into launches
+constexpr int CG2_VW_MAX = CG2_N_MAX / SCSAMD_BLOCK; // virtual update workgroups (vec_grid(n) for n <= CG2_N_MAX)
+
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg2_a(CsrView A, const real *__restrict__ ry, real *tmp, real *x,
+                                                       const real *__restrict__ r_old, real *r_new,
+                                                       const real *__restrict__ Gp, const real *__restrict__ M,
+                                                       const real *__restrict__ p_old, real *p_new_g, int n,
+                                                       const real *part_pgp, int cnt_pgp, int gv, CgCtl *ctl, int parity) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cg2_smem[];
+  real *pl = reinterpret_cast<real *>(cg2_smem); // n entries: z, then the new p
+  __shared__ real prod[NNZ_PER_BLOCK];
+  __shared__ real red[SCSAMD_BLOCK / SCSAMD_WAVE];
+  __shared__ real wz[CG2_VW_MAX][SCSAMD_BLOCK / SCSAMD_WAVE], wm[CG2_VW_MAX][SCSAMD_BLOCK / SCSAMD_WAVE];
+  __shared__ real vpz[CG2_VW_MAX], vpm[CG2_VW_MAX];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int NW = SCSAMD_BLOCK / SCSAMD_WAVE;
+  // everything this kernel reads before the product is requested up front
+  const int done = ctl->cg_done;
+  const real ztr_in = ctl->ztr[parity], tol = ctl->tol;
+  real psum = 0;
+  for (int i = tid; i < cnt_pgp; i += SCSAMD_BLOCK) psum += part_pgp[i];
+  if ((int)blockIdx.x < A.nblk) {
+    const int touch = A.rowblk[blockIdx.x + 1] ^ A.blkptr[blockIdx.x + 1];
+    asm volatile("" ::"v"(touch));
+  }
+  if (done) return;
+  const real pgp = block_sum(psum, red); // = reduce_partials_sum(part_pgp, cnt_pgp, red) of k_cg_update
+  const real alpha = ztr_in / pgp;
+  const int nv = n / RVW, gs = gv * SCSAMD_BLOCK;
+  const bool writer = blockIdx.x == 0;
+  // ---- update (k_cg_update), virtual workgroup by virtual workgroup: lane `tid` of virtual workgroup vw is global lane
+  // vw * 256 + tid and owns the vector chunk of that index (gs >= n: one chunk each) -- plus the scalar tail
+  // Virtual workgroups are taken four at a time with all their loads requested before anything is used (they are
+  // independent; one after the other they would cost a dependent read each).
+  constexpr int VB = 4;
+  for (int vw0 = 0; vw0 < gv; vw0 += VB) {
+    rvec Pq[VB], Gq[VB], Mq[VB], Rq[VB], Xq[VB];
+    bool okq[VB];
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int gtid = (vw0 + u) * SCSAMD_BLOCK + tid;
+      okq[u] = vw0 + u < gv && gtid < nv;
+      Pq[u] = Gq[u] = Mq[u] = Rq[u] = Xq[u] = rvec{};
+      if (okq[u]) {
+        Pq[u] = ldv(p_old, gtid);
+        Gq[u] = ldv(Gp, gtid);
+        Mq[u] = ldv(M, gtid);
+        Rq[u] = ldv(r_old, gtid);
+        if (writer) Xq[u] = ldv(x, gtid);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+      const int vw = vw0 + u;
+      if (vw >= gv) break;
+      const int gtid = vw * SCSAMD_BLOCK + tid;
+      real ztr = 0, mx = 0;
+      if (okq[u]) {
+        rvec R = Rq[u], X = Xq[u];
+#pragma unroll
+        for (int e = 0; e < RVW; ++e) {
+          X.v[e] += alpha * Pq[u].v[e];
+          const real ri = R.v[e] + (-alpha) * Gq[u].v[e];
+          R.v[e] = ri;
+          const real zi = ri * Mq[u].v[e];
+          pl[gtid * RVW + e] = zi;
+          ztr += zi * ri;
+          const real a = absval(ri);
+          mx = a > mx ? a : mx;
+        }
+        if (writer) {
+          stv(x, gtid, X);
+          stv(r_new, gtid, R);
+        }
+      }
+      for (int iv = gtid + gs; iv < nv; iv += gs) { // only when the vector grid is capped below n / 256
+        const rvec P = ldv(p_old, iv), G = ldv(Gp, iv), Mv = ldv(M, iv);
+        rvec R = ldv(r_old, iv);
+#pragma unroll
+        for (int e = 0; e < RVW; ++e) {
+          const real ri = R.v[e] + (-alpha) * G.v[e];
+          R.v[e] = ri;
+          const real zi = ri * Mv.v[e];
+          pl[iv * RVW + e] = zi;
+          ztr += zi * ri;
+          const real a = absval(ri);
+          mx = a > mx ? a : mx;
+        }
+        if (writer) {
+          rvec X = ldv(x, iv);
+#pragma unroll
+          for (int e = 0; e < RVW; ++e) X.v[e] += alpha * P.v[e];
+          stv(x, iv, X);
+          stv(r_new, iv, R);
+        }
+      }
+      for (int i = nv * RVW + gtid; i < n; i += gs) {
+        const real pi = p_old[i], gi = Gp[i];
+        const real ri = r_old[i] + (-alpha) * gi;
+        const real zi = ri * M[i];
+        pl[i] = zi;
+        ztr += zi * ri;
+        const real a = absval(ri);
+        mx = a > mx ? a : mx;
+        if (writer) {
+          x[i] += alpha * pi;
+          r_new[i] = ri;
+        }
+      }
+      // block_sum / block_max of the virtual workgroup: wave trees now, the cross-wave step after one barrier
+      ztr = wave_sum(ztr);
+      mx = wave_max(mx);
+      if (lane == 0) {
+        wz[vw][wave] = ztr;
+        wm[vw][wave] = mx;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < gv) {
+    real sz = wz[tid][0], sm = wm[tid][0];
+    for (int i = 1; i < NW; ++i) {
+      sz += wz[tid][i];
+      sm = wm[tid][i] > sm ? wm[tid][i] : sm;
+    }
+    vpz[tid] = sz; // = part_ztr[vw] of k_cg_update
+    vpm[tid] = sm; // = part_max[vw]
+  }
+  __syncthreads();
+  // ---- direction (k_cg_direction): same re-reduction of the partials, same tests
+  real zs = 0, ms = 0;
+  for (int i = tid; i < gv; i += SCSAMD_BLOCK) {
+    zs += vpz[i];
+    const real v = vpm[i];
+    ms = v > ms ? v : ms;
+  }
+  const real ztr = block_sum(zs, red);
+  const real nr = block_max(ms, red);
+  const bool conv = nr < tol;
+  const bool brk = !conv && ztr_in == (real)0;
+  if (!conv && !brk) {
+    const real beta = ztr / ztr_in;
+    for (int i = tid; i < n; i += SCSAMD_BLOCK) {
+      const real pn = pl[i] + beta * p_old[i];
+      pl[i] = pn;
+      if (writer) p_new_g[i] = pn;
+    }
+  }
+  if (writer && tid == 0) {
+    ctl->ztr[parity ^ 1] = ztr;
+    ctl->norm_r = nr;
+    if (!brk) ctl->iters += 1;
+    if (conv || brk || ctl->iters >= ctl->max_its) ctl->cg_done = 1;
+  }
+  if (conv || brk) return;
+  __syncthreads();
+  // ---- tmp = R_y^-1 A p, p gathered from LDS
+  EpiArgs e{ry, nullptr, nullptr, nullptr};
+  real dot = 0;
+  csr_stream_blocks<EPI_DIV>(A, pl, tmp, e, prod, red, blockIdx.x, gridDim.x, dot);
+}
+
+// ----------------------------------------------------------------------------
 // Tiny systems: the WHOLE scs_solve_lin_sys (private.c:284-324) in one launch of one
 // 1024-lane workgroup.  Below a few thousand nonzeros a CG iteration is four launches of
 // pure latency; one CU does the same work in less time and the per-batch host readback
@@ -598,6 +777,15 @@ void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s,
     // iterations from a captured graph instead (above it launches are hidden behind the kernels)
     use_graph = nnzA <= CG_GRAPH_MAX_NNZ;
     if (const char *e = getenv("SCS_AMD_GRAPH")) use_graph = atoi(e) != 0;
+    // two launches per CG iteration (k_cg2_a + the transposed product): n small enough for p in LDS, no P
+    use_cg2 = !use_fused && !has_P && n <= CG2_N_MAX && n >= 2 * RVW;
+    if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && n <= CG2_N_MAX && n >= 2 * RVW;
+    if (use_cg2) {
+      p2.alloc(n);
+      r2.alloc(n);
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cg2_a), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(CG2_N_MAX * sizeof(real))));
+    }
   }
   rx.alloc(n);
   ry.alloc(m);
@@ -670,6 +858,27 @@ void LinSys::harvest_timers() {
 // one PCG iteration = K1 (z = R_y^-1 A p), [P p], K2 (Gp, partial p'Gp), K3 (alpha, x, r, z, partial
 // z'r, |r|), K4 (stop test, beta, p); `b` is where the solve keeps x: always b_stage / the caller's
 // device vector, fixed per LinSys user, so it is passed through cg_x
+// small systems: iteration `it` >= 1 = k_cg2_a (update + direction of iteration it-1, then z = R_y^-1 A p_it) and the
+// transposed product; p_j lives in pbuf[j & 1].  Iteration 0 (no update yet) uses the plain A product.
+void LinSys::enqueue_cg2_iteration(long long it) {
+  CgCtl *c = ctl.p;
+  real *pbuf[2] = {p.p, p2.p}, *rbuf[2] = {r.p, r2.p};
+  const int gv = vec_grid(n);
+  const int gAt = At.grid();
+  real *p_cur = pbuf[it & 1];
+  if (it == 0) {
+    EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
+    launch_spmv(EPI_DIV, A, p_cur, tmp.p, e1, &c->cg_done);
+  } else {
+    const int q = (int)((it - 1) & 1);
+    hipLaunchKernelGGL(k_cg2_a, dim3(A.grid()), dim3(SCSAMD_BLOCK), (size_t)n * sizeof(real), stream, A.view(), ry.p, tmp.p, cg_x,
+                       rbuf[(it - 1) & 1], rbuf[it & 1], Gp.p, M.p, pbuf[(it - 1) & 1], p_cur, n, partA.p, gAt, gv, c, q);
+    n_spmv++;
+  }
+  EpiArgs e2{rx.p, p_cur, nullptr, partA.p};
+  launch_spmv(EPI_GP, At, tmp.p, Gp.p, e2, &c->cg_done);
+}
+
 void LinSys::enqueue_cg_iteration(int q) {
   CgCtl *c = ctl.p;
   const int gv = vec_grid(n);
@@ -702,7 +911,10 @@ bool LinSys::build_cg_graph() {
   }
   bool ok = true;
   try {
-    for (int j = 0; j < CG_GRAPH_ITERS; ++j) enqueue_cg_iteration(j & 1);
+    for (int j = 0; j < CG_GRAPH_ITERS; ++j) {
+      if (use_cg2) enqueue_cg2_iteration(1 + j); // replays always start at an odd iteration: same parity pattern
+      else enqueue_cg_iteration(j & 1);
+    }
   } catch (...) {
     ok = false;
   }
@@ -779,9 +991,15 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
   long long it = 0;
   int batch = std::max(4, std::min(last_its + 1, 4096));
   // partial arrays: partA <- p'Gp (K2), partB <- z'r and partB+PART_CAP/2 <- |r| (K3)
+  if (use_cg2) { // iteration 0 has no update to fold in; everything after it is k_cg2_a + the transposed product
+    enqueue_cg2_iteration(0);
+    it = 1;
+  }
   if (use_graph && !profiling && !cg_graph_tried) build_cg_graph();
   for (;;) {
-    int nb = (int)std::min<long long>(batch, max_its - it);
+    // cg2: the update/direction of iteration j runs inside iteration j+1's first kernel, so one more is enqueued
+    int nb = (int)std::min<long long>(batch, max_its + (use_cg2 ? 1 : 0) - it);
+    if (nb < 1) nb = 1;
     if (cg_graph && !profiling) {
       // whole graphs only (the parity of the double-buffered z'r slot restarts with each graph);
       // iterations enqueued past convergence are no-ops, as with individual launches
@@ -790,7 +1008,10 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
       n_graph_launches += ng;
       nb = ng * CG_GRAPH_ITERS;
     } else {
-      for (int j = 0; j < nb; ++j) enqueue_cg_iteration((int)((it + j) & 1));
+      for (int j = 0; j < nb; ++j) {
+        if (use_cg2) enqueue_cg2_iteration(it + j);
+        else enqueue_cg_iteration((int)((it + j) & 1));
+      }
     }
     it += nb;
     HIP_CHECK(hipMemcpyAsync(hctl.p, c, sizeof(CgCtl), hipMemcpyDeviceToHost, stream));
@@ -799,7 +1020,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
       fprintf(stderr, "[scs_amd pcg] enq=%lld iters=%d done=%d zero=%d |r|=%.3e tol=%.3e ztr=(%.3e,%.3e) |b|=%.3e\n",
               it, hctl.p->iters, hctl.p->cg_done, hctl.p->zero_rhs, (double)hctl.p->norm_r,
               (double)hctl.p->tol, (double)hctl.p->ztr[0], (double)hctl.p->ztr[1], (double)hctl.p->rhs_norm);
-    if (hctl.p->cg_done || it >= max_its) break;
+    if (hctl.p->cg_done || it >= max_its + (use_cg2 ? 1 : 0)) break;
     batch = std::max(4, std::min(last_its / 4 + 1, 1024));
   }
   const int its = hctl.p->iters;

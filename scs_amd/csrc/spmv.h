@@ -93,15 +93,13 @@ __device__ __forceinline__ void epi_apply_pre(real *y, int r, real acc, real dr,
 // comes from the Infinity Cache / HBM, ~1 us each), not by bandwidth: the loads that do not depend on each other
 // are therefore issued together -- {skip flag, row-block table entry}, then {entries, the lane's row pointers, its
 // epilogue operands}, then the gathers -- three round trips instead of seven.  Same arithmetic, same order.
+// the row-block loop of the stream product (shared by csr_stream_kernel and the small-system CG kernel of linsys.hip,
+// which gathers from an LDS copy of x): workgroup `b0` of `nb` strides over the row-blocks
 template <int EPI>
-__global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, const real *__restrict__ x,
-                                                                  real *y, EpiArgs e,
-                                                                  const int *skip) {
-  __shared__ real prod[NNZ_PER_BLOCK];
-  __shared__ real red[SCSAMD_BLOCK / SCSAMD_WAVE];
+__device__ __forceinline__ void csr_stream_blocks(const CsrView &A, const real *x, real *y, const EpiArgs &e, real *prod,
+                                                  real *red, int b0, int nb, real &dot) {
   const int tid = threadIdx.x;
-  int b = blockIdx.x;
-  const int sk = skip ? *skip : 0;
+  int b = b0;
   int r0 = 0, r1 = 0, k0 = 0, k1 = 0;
   if (b < A.nblk) {
     r0 = A.rowblk[b];
@@ -109,8 +107,6 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, con
     k0 = A.blkptr[b];
     k1 = A.blkptr[b + 1];
   }
-  if (sk) return;
-  real dot = 0;
   while (b < A.nblk) {
     const int cnt = k1 - k0;
     if (cnt > NNZ_PER_BLOCK) {
@@ -168,7 +164,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, con
       }
       __syncthreads();
     }
-    b += gridDim.x;
+    b += nb;
     if (b < A.nblk) {
       r0 = A.rowblk[b];
       r1 = A.rowblk[b + 1];
@@ -176,9 +172,26 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, con
       k1 = A.blkptr[b + 1];
     }
   }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, const real *__restrict__ x,
+                                                                  real *y, EpiArgs e,
+                                                                  const int *skip) {
+  __shared__ real prod[NNZ_PER_BLOCK];
+  __shared__ real red[SCSAMD_BLOCK / SCSAMD_WAVE];
+  // the skip flag and the first row-block's table entries are requested together (csr_stream_blocks starts with them)
+  const int sk = skip ? *skip : 0;
+  if ((int)blockIdx.x < A.nblk) { // in flight together with the flag: csr_stream_blocks then finds the lines in L1
+    const int touch = A.rowblk[blockIdx.x + 1] ^ A.blkptr[blockIdx.x + 1];
+    asm volatile("" ::"v"(touch));
+  }
+  if (sk) return;
+  real dot = 0;
+  csr_stream_blocks<EPI>(A, x, y, e, prod, red, blockIdx.x, gridDim.x, dot);
   if (EPI == EPI_GP && e.partial) {
     dot = block_sum(dot, red);
-    if (tid == 0) e.partial[blockIdx.x] = dot;
+    if (threadIdx.x == 0) e.partial[blockIdx.x] = dot;
   }
 }
 #endif // __HIPCC__

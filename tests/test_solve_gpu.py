@@ -328,3 +328,31 @@ def test_verbose_output_has_the_reference_layout(capfd):
         assert len(la) == 1 and len([l for l in r if l.startswith(key)]) == 1, key
         if pat:
             assert re.match(pat, la[0]), la[0]
+
+
+@pytest.mark.parametrize("shape", [(1000, 3000, 32), (400, 1200, 8), (1023, 2100, 10), (777, 1500, 6)])
+def test_two_launch_cg_path_is_bit_identical_to_the_four_kernel_path(shape, monkeypatch):
+    """n <= 1024: a CG iteration is k_cg2_a (update + direction of the previous iteration, redundantly in every
+    workgroup, then the A product out of LDS) + the transposed product instead of four kernels (linsys.hip).  Same
+    arithmetic down to the shape of every partial sum, so the whole solve -- default inexact CG schedule, where
+    any rounding difference would change iteration counts -- is bit-identical; also with graph replay off."""
+    amd = capi.load("libscsamd.so")
+    n, m, cn = shape
+    pr = problems.random_socp(n, m, cn, seed=n)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    kw = dict(verbose=0, acceleration_lookback=0, max_iters=150, eps_abs=1e-9, eps_rel=1e-9, want_stats=True)
+    monkeypatch.setenv("SCS_AMD_FUSED", "0")
+    outs = {}
+    for name, env in (("four", dict(SCS_AMD_CG2="0")), ("two", dict(SCS_AMD_CG2="1")),
+                      ("two_nograph", dict(SCS_AMD_CG2="1", SCS_AMD_GRAPH="0"))):
+        for k in ("SCS_AMD_CG2", "SCS_AMD_GRAPH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[name] = capi.solve(amd, prob, **kw)
+    for a, b in (("four", "two"), ("four", "two_nograph")):
+        ra, rb = outs[a], outs[b]
+        assert ra["stats"]["cg_iters"] == rb["stats"]["cg_iters"] > 0, (a, b)
+        assert ra["info"]["iter"] == rb["info"]["iter"]
+        for v in ("x", "y", "s"):
+            assert np.array_equal(ra[v], rb[v]), (a, b, v, np.abs(ra[v] - rb[v]).max())
