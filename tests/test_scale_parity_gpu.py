@@ -133,3 +133,28 @@ def test_reference_random_socp_prob_program_over_our_library():
     assert abs(opt - dopt) <= 1e-6 * max(1.0, abs(opt))            # the generator's certificate
     assert abs(got - opt) <= 2e-3 * max(1.0, abs(opt)), (got, opt)  # eps = 1e-4 solve
     assert abs(gotd - opt) <= 2e-3 * max(1.0, abs(opt)), (gotd, opt)
+
+
+def test_sdp_with_blocks_beyond_the_lds_path_matches_reference_exact_cg():
+    """PSD blocks of order 120 and 97 (chip-wide Jacobi steps, psd_big.h, warm-started from the previous eigenbasis
+    inside the solve) next to 40x40 blocks (LDS kernel) and a box cone: same trajectory as the reference (LAPACK dsyevr)
+    with exact linear solves -- equal iteration count, 1e-6 on every ScsInfo field and on x, y, s."""
+    ref = _ref("libscsindir_ref_exactcg.so")
+    amd = capi.load("libscsamd.so")
+    cone = dict(z=0, l=0, bu=np.ones(50), bl=-np.ones(50), bsize=51, q=[], s=[120, 40, 97, 40])
+    m = 51 + sum(k * (k + 1) // 2 for k in cone["s"])
+    pr = problems.random_cone_prob(600, m, 8, cone, seed=77)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    kw = dict(verbose=0, acceleration_lookback=0, max_iters=120)
+    ra = capi.solve(amd, prob, cg_tol_override=1e-12, want_stats=True, **kw)
+    rr = capi.solve(ref, prob, **kw)
+    ia, ir = ra["info"], rr["info"]
+    assert ia["iter"] == ir["iter"], (ia["iter"], ir["iter"])
+    assert ia["status_val"] == ir["status_val"]
+    assert ia["scale_updates"] == ir["scale_updates"]
+    for k in ("pobj", "dobj", "res_pri", "res_dual", "scale"):
+        assert _rel(ia[k], ir[k]) <= REL, (k, ia[k], ir[k])
+    for v in ("x", "y", "s"):
+        d = np.abs(ra[v] - rr[v]).max() / max(1.0, np.abs(rr[v]).max())
+        assert d <= REL, (v, d)
+    assert ra["stats"]["psd_unconverged"] == 0
