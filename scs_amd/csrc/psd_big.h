@@ -186,39 +186,6 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_update(BigPsdView B, int step
   }
 }
 
-// Before a sweep: a block whose off-diagonal entries (rows and columns < k) are all at or below the threshold is
-// finished -- exactly what a whole sweep without a single rotation would conclude (it visits the same entries and
-// changes none), for one pass over A instead of K2 - 1 steps.  One workgroup per block; *remaining = blocks still
-// iterating (written by block 0 after every block's flag is final: single workgroup grid over blocks, in order).
-__global__ __launch_bounds__(BP_PARAM_THREADS) void k_bp_precheck(BigPsdView B, int *remaining) {
-  __shared__ real red[BP_PARAM_THREADS / SCSAMD_WAVE];
-  int rem = 0;
-  for (int b = 0; b < B.nbig; ++b) {
-    BigPsdCtl *c = B.ctl + b;
-    if (c->done) continue;
-    const BlockShape s = bp_shape_raw(c->kraw);
-    const real *A = B.A + (size_t)b * B.ld * B.ld;
-    const real thr = c->thr;
-    real mx = 0;
-    const long long total = (long long)s.k * s.k;
-    for (long long e = threadIdx.x; e < total; e += BP_PARAM_THREADS) {
-      const int i = (int)(e % s.k), j = (int)(e / s.k);
-      if (i < j) { // the entry the rotation of pair (p = i, q = j) reads: row p, column q
-        const real a = absval(A[(size_t)j * B.ld + i]);
-        mx = a > mx ? a : mx;
-      }
-    }
-    mx = block_max(mx, red);
-    if (mx <= thr) {
-      if (threadIdx.x == 0) c->done = 1;
-    } else {
-      ++rem;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *remaining = rem;
-}
-
 // closes a sweep for every block; *remaining = blocks still iterating
 __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -477,19 +444,14 @@ struct BigPsd {
     int h_rem = nbig;
     const long long sweeps_before = sweeps_total;
     for (int sweep = 0; sweep < PSD_MAX_SWEEPS && h_rem > 0; ++sweep) {
-      if (sweep > 0) { // the first sweep always has work; later ones are skipped when nothing is above the threshold
-        hipLaunchKernelGGL(k_bp_precheck, dim3(1), dim3(BP_PARAM_THREADS), 0, st, B, remaining.p);
-        HIP_CHECK(hipMemcpyAsync(&h_rem, remaining.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (h_rem == 0) break;
-      }
       for (int step = 0; step < ld - 1; ++step) {
         hipLaunchKernelGGL(k_bp_params, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B, step);
         hipLaunchKernelGGL(k_bp_update, dim3(g_upd, nbig), dim3(BP_THREADS), 0, st, B, step);
       }
       hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p);
+      HIP_CHECK(hipMemcpyAsync(&h_rem, remaining.p, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
       ++sweeps_total;
-      h_rem = nbig; // decided by the next precheck (or by the sweep cap through the loop bound)
     }
     ++projections;
     static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
