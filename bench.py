@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--batch-concurrency", type=int, default=4)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # gloo: launch-path self test on CPU
     ap.add_argument("--stub-solver", action="store_true", help=argparse.SUPPRESS)  # no GPU: fake solver, same scaffolding
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional test of the N-rank path on a box with fewer GPUs than ranks: rank r uses GPU r %% visible GPUs "
+                         "and the collectives run over gloo (RCCL refuses two ranks on one device); the JSON says so")
     return ap.parse_args()
 
 
@@ -435,10 +438,13 @@ def main():
     if not stub:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+        if args.share_gpu:
+            local_rank = local_rank % torch.cuda.device_count()
+            args.backend = "gloo"
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
         torch.cuda.set_device(local_rank)
-    dev = "cpu" if stub else "cuda"
+    dev = "cpu" if (stub or args.share_gpu) else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -578,6 +584,7 @@ def main():
             "unit": "ADMM iters/sec",
             "n_gpus": world,
             "rccl_ranks_seen": ranks_seen,
+            **({"share_gpu": "functional test: %d ranks on %d GPU(s), collectives over gloo -- not a scaling measurement" % (world, torch.cuda.device_count())} if args.share_gpu else {}),
             "steps": K,
             "warmup": W,
             "ms_per_step": 1e3 * elapsed_max / max(steps_done, 1),
