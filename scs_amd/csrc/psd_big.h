@@ -5,15 +5,16 @@
 //
 // Per big block (all in HBM, column-major, common leading dimension ld = even-padded largest order):
 //   A (K2 x K2 working matrix), V (eigenvectors), rotation tables of one step, a small control record.
-// One Jacobi step = two launches over all big blocks (blockIdx.y = block):
-//   k_bp_params  one workgroup per block: the K2/2 disjoint rotations of round-robin step `step` from the current A
-//                (same formulas, same threshold rule, same round-robin order as the LDS kernel), "does anything
-//                rotate" flag, running max of the off-diagonal entries met in this sweep
-//   k_bp_update  chip-wide: A <- J' A J as independent 2x2 blocks (one lane each) and V <- V J, lanes walking rows
-//                (consecutive addresses); returns at once for converged blocks / steps without rotation
+// One Jacobi step = ONE launch over all big blocks (blockIdx.y = block), k_bp_step: A is double-buffered (the step reads
+// the matrix as it stood when the step began and writes the other copy), so every workgroup can form the rotations it
+// needs straight from A without racing the workgroups that are rewriting those entries -- no separate "parameters"
+// launch and no tables.  A workgroup owns a 16 x 16 tile of (row pair, column pair) 2x2 blocks (lanes 0-31 form its 32
+// rotations once, everybody reads them from LDS) or a 64-row x 4-pair tile of V; same formulas, same threshold rule,
+// same round-robin order, same exact zero for a rotated pair's own entry as the LDS kernel.  The running maximum of the
+// off-diagonal entries met in a sweep is an atomic max (order-independent, so still deterministic).
 // k_bp_sweep_end closes a sweep (convergence, sweep cap as in cones.c:1031), the host reads one int per sweep.
-// A step costs ~10 us whatever the order (two dependent launches, each ~3.5 us at least because it hands data to the
-// next one; replaying a sweep from a HIP graph measured no faster), so the time is steps x sweeps.
+// A step costs ~5 us however small the block (a kernel that hands data to the next one), so the time is steps x sweeps;
+// the earlier two-launch form (parameters, then update) took ~10 us per step.
 // Reconstruction X+ = W W' (W = V diag(sqrt(max(lambda, 0)))) runs on the fp64 matrix cores over all CUs (k_bp_gram).
 // Everything is deterministic: no atomics in sums, one workgroup owns every reduction.
 //
@@ -23,8 +24,9 @@
 namespace scsamd {
 
 struct BigPsdCtl {
-  real thr, fro, offmax;
-  int any[2];
+  real thr, fro;
+  unsigned long long offmax_bits; // bit pattern of the largest |a_pq| met in this sweep (non-negative: orders like the value)
+  int cur[2];                     // which A copy holds the block before launch g: cur[g & 1] (written for g+1 by the launch itself)
   int done, sweeps, kraw; // kraw: signed order (negative = complex embedding), copied here so that a step kernel
                           // needs ONE dependent read (this record) before it touches A
 };
@@ -36,9 +38,8 @@ struct BigPsdView {
   int nbig, ld;           // blocks, common leading dimension (= K2 of the largest)
   const int *id;          // index of each big block in psd_off / psd_k
   const int *psd_off, *psd_k;
-  real *A, *V;            // nbig * ld * ld each
-  RotCS *rot_cs;          // nbig * ld / 2
-  int2 *rot_pq;
+  real *A, *V;            // nbig * ld * ld each (A: copy 0 of the working matrix)
+  real *A1;               // copy 1 of the working matrix
   BigPsdCtl *ctl;         // nbig
 };
 
@@ -90,95 +91,138 @@ __global__ __launch_bounds__(BP_PARAM_THREADS) void k_bp_norm(BigPsdView B) {
     c->fro = fro;
     // same rule as k_psd_jacobi (fp32: not below the rounding noise of the rotations)
     c->thr = sizeof(real) == 8 ? eps * fro / (real)s.k : fmaxf(eps * fro / (real)s.k, (real)2.4e-7 * fro);
-    c->offmax = 0;
-    c->any[0] = c->any[1] = 0;
+    c->offmax_bits = 0ull;
+    c->cur[0] = c->cur[1] = 0;
     c->done = fro > (real)0 ? 0 : 1;
     c->sweeps = 0;
     c->kraw = B.psd_k[B.id[b]];
   }
 }
 
-// rotations of one round-robin step
-__global__ __launch_bounds__(BP_PARAM_THREADS) void k_bp_params(BigPsdView B, int step) {
-  __shared__ real red[BP_PARAM_THREADS / SCSAMD_WAVE];
-  const int b = blockIdx.y;
-  BigPsdCtl *ctl = B.ctl + b;
-  if (ctl->done) return;
-  const BlockShape sh = bp_shape_raw(ctl->kraw);
-  if (step >= sh.K2 - 1) return; // smaller block than the largest: its sweep has fewer steps
-  const real *A = B.A + (size_t)b * B.ld * B.ld;
-  RotCS *rot_cs = B.rot_cs + (size_t)b * (B.ld / 2);
-  int2 *rot_pq = B.rot_pq + (size_t)b * (B.ld / 2);
-  const real thr = ctl->thr;
-  const int K2 = sh.K2, k = sh.k, ld = B.ld;
-  real offmax = 0;
-  int any = 0;
-  for (int i = threadIdx.x; i < sh.npairs; i += BP_PARAM_THREADS) {
-    int p = i == 0 ? 0 : 1 + ((i - 1 + step) % (K2 - 1));
-    int q = 1 + ((K2 - 2 - i + step) % (K2 - 1));
-    if (p > q) {
-      const int t = p;
-      p = q;
-      q = t;
-    }
-    real c = 1, s = 0;
-    const real apq = A[(size_t)q * ld + p];
-    const real aa = absval(apq);
-    if (q < k) offmax = aa > offmax ? aa : offmax;
-    if (q < k && aa > thr) {
-      const real d = A[(size_t)q * ld + q] - A[(size_t)p * ld + p], bb = (real)2 * apq;
-      const real h = sqrt(d * d + bb * bb);
-      const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
-      c = rsqrt(t * t + (real)1);
-      s = t * c;
-      any = 1;
-    }
-    rot_pq[i] = make_int2(p, q);
-    rot_cs[i] = RotCS{c, s};
-  }
-  any = __syncthreads_or(any);
-  offmax = block_max(offmax, red);
-  if (threadIdx.x == 0) {
-    ctl->any[step & 1] = any;
-    if (offmax > ctl->offmax) ctl->offmax = offmax;
-  }
+__device__ __forceinline__ unsigned long long bp_bits(real v) { // v >= 0
+  return sizeof(real) == 8 ? (unsigned long long)__double_as_longlong((double)v) : (unsigned long long)__float_as_uint((float)v);
+}
+__device__ __forceinline__ real bp_from_bits(unsigned long long b) {
+  return sizeof(real) == 8 ? (real)__longlong_as_double((long long)b) : (real)__uint_as_float((unsigned)b);
 }
 
-__global__ __launch_bounds__(BP_THREADS) void k_bp_update(BigPsdView B, int step) {
-  const int b = blockIdx.y;
-  const BigPsdCtl *ctl = B.ctl + b;
-  if (ctl->done || !ctl->any[step & 1]) return;
-  const BlockShape sh = bp_shape_raw(ctl->kraw);
-  if (step >= sh.K2 - 1) return;
-  real *A = B.A + (size_t)b * B.ld * B.ld, *V = B.V + (size_t)b * B.ld * B.ld;
-  const RotCS *rot_cs = B.rot_cs + (size_t)b * (B.ld / 2);
-  const int2 *rot_pq = B.rot_pq + (size_t)b * (B.ld / 2);
-  const int npairs = sh.npairs, K2 = sh.K2;
-  const size_t ld = B.ld;
-  const long long nblk = (long long)npairs * npairs, nv = (long long)K2 * npairs;
-  for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < nblk + nv; e += (long long)gridDim.x * BP_THREADS) {
-    if (e < nblk) {
+// rotation of pair i of round-robin step `step`, from the matrix as it stands before the step
+__device__ __forceinline__ void bp_rotation(const real *Aold, size_t ld, int i, int step, int K2, int k, real thr, int2 &pq,
+                                            RotCS &cs, real &aa_out) {
+  int p = i == 0 ? 0 : 1 + ((i - 1 + step) % (K2 - 1));
+  int q = 1 + ((K2 - 2 - i + step) % (K2 - 1));
+  if (p > q) {
+    const int t = p;
+    p = q;
+    q = t;
+  }
+  real c = 1, s = 0;
+  const real apq = Aold[q * ld + p], aqq = Aold[q * ld + q], app = Aold[p * ld + p];
+  const real aa = absval(apq);
+  aa_out = q < k ? aa : (real)0;
+  if (q < k && aa > thr) {
+    // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the first division
+    const real d = aqq - app, bb = (real)2 * apq;
+    const real h = sqrt(d * d + bb * bb);
+    const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
+    c = rsqrt(t * t + (real)1);
+    s = t * c;
+  }
+  pq = make_int2(p, q);
+  cs = RotCS{c, s};
+}
+
+constexpr int BP_TILE = 16;   // a workgroup's tile of 2x2 blocks: 16 row pairs x 16 column pairs
+constexpr int BP_VROWS = 64;  // V tile: 64 rows x 4 pairs
+constexpr int BP_VPAIRS = BP_THREADS / BP_VROWS;
+
+// arg = (launch parity) | (round-robin step << 1): the control record's `cur` is double-buffered by LAUNCH parity (a sweep
+// of the largest block has an odd or even number of steps), the pairing follows the step
+__global__ __launch_bounds__(BP_THREADS) void k_bp_step(BigPsdView B, int arg) {
+  const int slot = arg & 1, step = arg >> 1;
+  __shared__ int2 s_pq[2 * BP_TILE];
+  __shared__ RotCS s_cs[2 * BP_TILE];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  BigPsdCtl *ctl = B.ctl + b;
+  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
+  const real thr = ctl->thr;
+  const BlockShape sh = bp_shape_raw(kraw);
+  const bool active = !done && step < sh.K2 - 1; // a block smaller than the largest has fewer steps per sweep
+  if (blockIdx.x == 0 && tid == 0) ctl->cur[slot ^ 1] = active ? cur ^ 1 : cur;
+  if (!active) return;
+  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
+  const real *Aold = (cur ? B.A1 : B.A) + mat;
+  real *Anew = (cur ? B.A : B.A1) + mat;
+  real *V = B.V + mat;
+  const int npairs = sh.npairs, K2 = sh.K2, k = sh.k;
+  const int TP = (npairs + BP_TILE - 1) / BP_TILE;
+  const int nta = TP * TP;
+  const int TQv = (npairs + BP_VPAIRS - 1) / BP_VPAIRS, TR = (K2 + BP_VROWS - 1) / BP_VROWS;
+  int tile = blockIdx.x;
+  if (tile < nta) {
+    // ---- A <- J' A J on a 16 x 16 tile of 2x2 blocks: rows of pairs [16 tp, +16), columns of pairs [16 tq, +16)
+    const int tq = tile / TP, tp = tile % TP;
+    if (tid < 2 * BP_TILE) {
+      const int i = tid < BP_TILE ? BP_TILE * tp + tid : BP_TILE * tq + (tid - BP_TILE);
+      int2 pq = make_int2(0, 0);
+      RotCS cs{(real)1, (real)0};
+      real aa = 0;
+      if (i < npairs) bp_rotation(Aold, ld, i, step, K2, k, thr, pq, cs, aa);
+      s_pq[tid] = pq;
+      s_cs[tid] = cs;
+      // every pair is a "row pair" of exactly the tiles with tq == 0: they carry the sweep's off-diagonal maximum
+      if (tq == 0 && tid < BP_TILE) {
+        real mx = aa;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          const real w = __shfl_down(mx, o, 64);
+          mx = w > mx ? w : mx;
+        }
+        if (tid == 0 && mx > (real)0) atomicMax(&ctl->offmax_bits, bp_bits(mx));
+      }
+    }
+    __syncthreads();
+    const int lp = tid & (BP_TILE - 1), lq = tid >> 4;
+    const int P = BP_TILE * tp + lp, Q = BP_TILE * tq + lq;
+    if (P < npairs && Q < npairs) {
       // consecutive lanes walk the ROW pairs: consecutive p1 (and q1) -> consecutive addresses in column-major storage
-      const int Q = (int)(e / npairs), P = (int)(e % npairs);
-      const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
-      const RotCS r1 = rot_cs[P], r2 = rot_cs[Q];
+      const int2 pq1 = s_pq[lp], pq2 = s_pq[BP_TILE + lq];
+      const RotCS r1 = s_cs[lp], r2 = s_cs[BP_TILE + lq];
       const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
       const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
       const size_t i11 = p2 * ld + p1, i12 = q2 * ld + p1, i21 = p2 * ld + q1, i22 = q2 * ld + q1;
-      const real a11 = A[i11], a12 = A[i12], a21 = A[i21], a22 = A[i22];
+      const real a11 = Aold[i11], a12 = Aold[i12], a21 = Aold[i21], a22 = Aold[i22];
       const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
       const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
       const bool own = P == Q && s1 != (real)0; // the rotated pair's own off-diagonal entry: exact zero
-      A[i11] = c2 * r11 - s2 * r12;
-      A[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
-      A[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
-      A[i22] = s2 * r21 + c2 * r22;
-    } else {
-      const long long f = e - nblk;
-      const int Q = (int)(f / K2), i = (int)(f % K2);
-      const int2 pq2 = rot_pq[Q];
-      const RotCS r2 = rot_cs[Q];
-      const size_t ip = pq2.x * ld + i, iq = pq2.y * ld + i;
+      Anew[i11] = c2 * r11 - s2 * r12;
+      Anew[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
+      Anew[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
+      Anew[i22] = s2 * r21 + c2 * r22;
+    }
+    return;
+  }
+  tile -= nta;
+  if (tile >= TQv * TR) return;
+  // ---- V <- V J on a tile of 64 rows x 4 pairs (in place: a lane owns its two entries)
+  const int tqv = tile / TR, tr = tile % TR;
+  if (tid < BP_VPAIRS) {
+    const int i = BP_VPAIRS * tqv + tid;
+    int2 pq = make_int2(0, 0);
+    RotCS cs{(real)1, (real)0};
+    real aa = 0;
+    if (i < npairs) bp_rotation(Aold, ld, i, step, K2, k, thr, pq, cs, aa);
+    s_pq[tid] = pq;
+    s_cs[tid] = cs;
+  }
+  __syncthreads();
+  const int li = tid & (BP_VROWS - 1), lq = tid >> 6;
+  const int row = BP_VROWS * tr + li, Q = BP_VPAIRS * tqv + lq;
+  if (row < K2 && Q < npairs) {
+    const int2 pq2 = s_pq[lq];
+    const RotCS r2 = s_cs[lq];
+    if (r2.s != (real)0) {
+      const size_t ip = pq2.x * ld + row, iq = pq2.y * ld + row;
       const real vp = V[ip], vq = V[iq];
       V[ip] = r2.c * vp - r2.s * vq;
       V[iq] = r2.s * vp + r2.c * vq;
@@ -194,7 +238,7 @@ __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
     BigPsdCtl *c = B.ctl + b;
     if (c->done) continue;
     c->sweeps += 1;
-    if (c->offmax <= c->thr) {
+    if (bp_from_bits(c->offmax_bits) <= c->thr) {
       c->done = 1;
     } else if (c->sweeps >= PSD_MAX_SWEEPS) {
       c->done = 1;
@@ -202,16 +246,16 @@ __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
     } else {
       ++rem;
     }
-    c->offmax = 0;
+    c->offmax_bits = 0ull;
   }
   *remaining = rem;
 }
 
 // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044), in place
-__global__ __launch_bounds__(BP_THREADS) void k_bp_scale(BigPsdView B) {
+__global__ __launch_bounds__(BP_THREADS) void k_bp_scale(BigPsdView B, int slot) {
   const int b = blockIdx.y;
   const BlockShape s = bp_shape(B, b);
-  const real *A = B.A + (size_t)b * B.ld * B.ld;
+  const real *A = (B.ctl[b].cur[slot] ? B.A1 : B.A) + (size_t)b * B.ld * B.ld; // the copy the last step left the block in
   real *V = B.V + (size_t)b * B.ld * B.ld;
   const long long total = (long long)s.K2 * s.K2;
   for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * BP_THREADS) {
@@ -374,11 +418,9 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_symm(BigPsdView B) {
 struct BigPsd {
   int nbig = 0, kmax = 0, ld = 0;
   DevBuf<int> id;
-  DevBuf<real> A, V, Vp, Tm; // working matrix, eigenvectors / W, carried eigenbasis, warm-start temporary
+  DevBuf<real> A, V, Vp, Tm; // working matrix (copy 0), eigenvectors / W, carried eigenbasis, warm-start temporary = copy 1 of A
   bool have_basis = false;
   long long calls = 0;
-  DevBuf<RotCS> rot_cs;
-  DevBuf<int2> rot_pq;
   DevBuf<BigPsdCtl> ctl;
   DevBuf<int> remaining;
   long long sweeps_total = 0, projections = 0;
@@ -404,14 +446,10 @@ struct BigPsd {
     A.alloc((size_t)nbig * ld * ld);
     V.alloc((size_t)nbig * ld * ld);
     warm_ok = !getenv("SCS_AMD_PSD_COLD");
-    if (warm_ok) {
-      Vp.alloc((size_t)nbig * ld * ld);
-      Tm.alloc((size_t)nbig * ld * ld);
-    }
+    if (warm_ok) Vp.alloc((size_t)nbig * ld * ld);
+    Tm.alloc((size_t)nbig * ld * ld); // T of the warm start, then the second copy of A during the sweeps
     have_basis = false;
     calls = 0;
-    rot_cs.alloc((size_t)nbig * (ld / 2));
-    rot_pq.alloc((size_t)nbig * (ld / 2));
     ctl.alloc(nbig);
     remaining.alloc(1);
     HIP_CHECK(hipStreamSynchronize(st));
@@ -420,11 +458,11 @@ struct BigPsd {
   // x: the cone vector (device); status: the ConeDev sweep-cap counter
   void project(real *x, const int *psd_off, const int *psd_k, int *status, hipStream_t st) {
     if (!nbig) return;
-    BigPsdView B{nbig, ld, id.p, psd_off, psd_k, A.p, V.p, rot_cs.p, rot_pq.p, ctl.p};
+    BigPsdView B{nbig, ld, id.p, psd_off, psd_k, A.p, V.p, Tm.p, ctl.p};
     const long long elems = (long long)ld * ld;
     const int g_elem = (int)std::min<long long>((elems + BP_THREADS - 1) / BP_THREADS, 2048);
-    const long long items = (long long)(ld / 2) * (ld / 2) + (long long)ld * (ld / 2);
-    const int g_upd = (int)std::min<long long>((items + BP_THREADS - 1) / BP_THREADS, 4096);
+    const int np_max = ld / 2, TPm = (np_max + BP_TILE - 1) / BP_TILE;
+    const int g_step = TPm * TPm + ((np_max + BP_VPAIRS - 1) / BP_VPAIRS) * ((ld + BP_VROWS - 1) / BP_VROWS); // tiles of the largest block
     // warm start (as in the LDS kernel): iterate on A' = Vp' A Vp from V = Vp, the eigenbasis of the previous projection
     // of the same block; a cold restart every PSD_WARM_RESET calls bounds the orthogonality drift of the carried basis
     const bool warm = warm_ok && have_basis && (calls % PSD_WARM_RESET) != 0;
@@ -442,12 +480,11 @@ struct BigPsd {
     }
     hipLaunchKernelGGL(k_bp_norm, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B);
     int h_rem = nbig;
+    long long gstep = 0; // launches so far: the copy of A a block is in alternates with the steps IT took (ctl.cur)
     const long long sweeps_before = sweeps_total;
     for (int sweep = 0; sweep < PSD_MAX_SWEEPS && h_rem > 0; ++sweep) {
-      for (int step = 0; step < ld - 1; ++step) {
-        hipLaunchKernelGGL(k_bp_params, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B, step);
-        hipLaunchKernelGGL(k_bp_update, dim3(g_upd, nbig), dim3(BP_THREADS), 0, st, B, step);
-      }
+      for (int step = 0; step < ld - 1; ++step, ++gstep)
+        hipLaunchKernelGGL(k_bp_step, dim3(g_step, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1) | (step << 1));
       hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p);
       HIP_CHECK(hipMemcpyAsync(&h_rem, remaining.p, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
@@ -460,7 +497,7 @@ struct BigPsd {
       HIP_CHECK(hipMemcpyAsync(Vp.p, V.p, mat_bytes, hipMemcpyDeviceToDevice, st));
       have_basis = true;
     }
-    hipLaunchKernelGGL(k_bp_scale, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B);
+    hipLaunchKernelGGL(k_bp_scale, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1));
     const long long T = (kmax + 15) / 16, ntile = T * (T + 1) / 2;
     const long long outs = (long long)kmax * (kmax + 1) / 2;
     const int g_gram = (int)std::min<long long>(std::max<long long>((ntile + 3) / 4, (outs + 64LL * BP_THREADS - 1) / (64LL * BP_THREADS)), 8192);
