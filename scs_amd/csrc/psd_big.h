@@ -4,7 +4,7 @@
 // limit other than memory.  Included by cones.hip only (uses its RotCS, packed_index, psd_unpack_entry).
 //
 // Per big block (all in HBM, column-major, common leading dimension ld = even-padded largest order):
-//   A (K2 x K2 working matrix), V (eigenvectors), rotation tables of one step, a small control record.
+//   two copies of A (K2 x K2 working matrix), V (eigenvectors), the carried eigenbasis, a small control record.
 // One Jacobi step = ONE launch over all big blocks (blockIdx.y = block), k_bp_step: A is double-buffered (the step reads
 // the matrix as it stood when the step began and writes the other copy), so every workgroup can form the rotations it
 // needs straight from A without racing the workgroups that are rewriting those entries -- no separate "parameters"
@@ -16,7 +16,7 @@
 // A step costs ~5 us however small the block (a kernel that hands data to the next one), so the time is steps x sweeps;
 // the earlier two-launch form (parameters, then update) took ~10 us per step.
 // Reconstruction X+ = W W' (W = V diag(sqrt(max(lambda, 0)))) runs on the fp64 matrix cores over all CUs (k_bp_gram).
-// Everything is deterministic: no atomics in sums, one workgroup owns every reduction.
+// Everything is deterministic: no atomics in sums (the one atomic is a max), one workgroup owns every reduction.
 //
 // Measured (profiles/r2_bench_psd_sizes_*.jsonl): see DESIGN.md section 6.
 #pragma once
