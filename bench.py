@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional test of the N-rank path on a box with fewer GPUs than ranks: rank r uses GPU r %% visible GPUs "
                          "and the collectives run over gloo (RCCL refuses two ranks on one device); the JSON says so")
+    if not sys.argv[1:] and os.environ.get("SCS_BENCH_ARGV"):  # re-executed by respawn(): see there
+        return ap.parse_args(json.loads(os.environ["SCS_BENCH_ARGV"]))
     return ap.parse_args()
 
 
@@ -306,8 +308,11 @@ def respawn(args):
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the script's own options travel in the environment: torch.distributed.run's parser claims abbreviations of ITS
+    # options even after the script path (`--n 20000` is "ambiguous" to it)
+    env["SCS_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
