@@ -31,9 +31,11 @@
  * Plain C types only: pointers, sizes, the structs below.  No HIP or torch type
  * crosses this boundary.  Struct layouts are ABI facts of the reference and are
  * restated field-for-field (include/scs.h:47-244, include/aa_stats.h:21-42,
- * include/scs_types.h:13-32); scs_int is 32-bit (DLONG builds are not
- * supported by this backend and scs_init refuses nothing silently: the header
- * simply does not offer the 64-bit typedef).
+ * include/scs_types.h:13-32).  scs_int is 32-bit by default and 64-bit when the
+ * header is compiled with -DDLONG, exactly like the reference's own switch; the
+ * matching library is libscsamd_dlong.so (same entry points, 64-bit indices and
+ * sizes at this boundary; the device keeps 32-bit indices, so a problem still
+ * needs nnz(A) < 2^31 and scs_init refuses larger ones loudly).
  */
 #ifndef SCS_AMD_H
 #define SCS_AMD_H
@@ -43,7 +45,11 @@ extern "C" {
 #endif
 
 /* ---- primitive types (reference include/scs_types.h:13-32) ------------- */
+#ifdef DLONG
+typedef long long scs_int; /* reference -DDLONG, include/scs_types.h:13-20 */
+#else
 typedef int scs_int;
+#endif
 #ifndef SFLOAT
 typedef double scs_float;
 #else

@@ -19,8 +19,9 @@ LIB_DIR = os.path.join(_HERE, "lib")
 scs_int = C.c_int
 
 
-def make_types(ftype):
-    """Build the struct family for scs_float = ftype (c_double or c_float)."""
+def make_types(ftype, scs_int=C.c_int):
+    """Build the struct family for scs_float = ftype (c_double or c_float) and scs_int (c_int, or c_longlong
+    for the -DDLONG library)."""
     fp = C.POINTER(ftype)
     ip = C.POINTER(scs_int)
 
@@ -84,8 +85,9 @@ def make_types(ftype):
         ]
 
     ns = type("ScsTypes", (), {})
-    ns.ftype, ns.fp, ns.ip = ftype, fp, ip
+    ns.ftype, ns.fp, ns.ip, ns.scs_int = ftype, fp, ip, scs_int
     ns.np_float = np.float64 if ftype is C.c_double else np.float32
+    ns.np_int = np.int32 if scs_int is C.c_int else np.int64
     ns.ScsMatrix, ns.ScsSettings, ns.ScsData, ns.ScsCone = ScsMatrix, ScsSettings, ScsData, ScsCone
     ns.ScsSolution, ns.AaStats, ns.ScsInfo, ns.ScsAmdStats = ScsSolution, AaStats, ScsInfo, ScsAmdStats
     return ns
@@ -93,11 +95,13 @@ def make_types(ftype):
 
 T64 = make_types(C.c_double)
 T32 = make_types(C.c_float)
+T64L = make_types(C.c_double, C.c_longlong)  # libscsamd_dlong.so
 
 
 def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
     """Attach argtypes/restypes for every entry point the library exports."""
     fp = T.fp
+    scs_int = T.scs_int
     if full:
         lib.scs_init.restype = C.c_void_p
         lib.scs_init.argtypes = [C.POINTER(T.ScsData), C.POINTER(T.ScsCone), C.POINTER(T.ScsSettings)]
@@ -178,7 +182,7 @@ def load(name="libscsamd.so"):
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "There is no CPU fallback in the product path.")
     lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
-    T = T32 if name.endswith("_f32.so") else T64
+    T = T32 if name.endswith("_f32.so") else (T64L if name.endswith("_dlong.so") else T64)
     only_linsys = "linsys" in name
     bind_api(lib, T, full=not only_linsys, linsys=True, cones=not only_linsys, stats=True)
     _cache[name] = lib
@@ -199,8 +203,8 @@ class Problem:
         A.sort_indices()
         self.m, self.n = A.shape
         self.Ax = np.ascontiguousarray(A.data, dtype=f)
-        self.Ai = np.ascontiguousarray(A.indices, dtype=np.int32)
-        self.Ap = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        self.Ai = np.ascontiguousarray(A.indices, dtype=T.np_int)
+        self.Ap = np.ascontiguousarray(A.indptr, dtype=T.np_int)
         self.b = np.ascontiguousarray(b, dtype=f)
         self.c = np.ascontiguousarray(c, dtype=f)
         self.cone = dict(cone)
@@ -211,8 +215,8 @@ class Problem:
             P = sp.csc_matrix(sp.triu(P))
             P.sort_indices()
             self.Px = np.ascontiguousarray(P.data, dtype=f)
-            self.Pi = np.ascontiguousarray(P.indices, dtype=np.int32)
-            self.Pp = np.ascontiguousarray(P.indptr, dtype=np.int32)
+            self.Pi = np.ascontiguousarray(P.indices, dtype=T.np_int)
+            self.Pp = np.ascontiguousarray(P.indptr, dtype=T.np_int)
             self.matP = T.ScsMatrix(self.Px.ctypes.data_as(T.fp), self.Pi.ctypes.data_as(T.ip),
                                     self.Pp.ctypes.data_as(T.ip), self.n, self.n)
         self.data = T.ScsData(self.m, self.n, C.pointer(self.matA),
@@ -236,10 +240,10 @@ def make_cone(cone, T=T64, keep=None):
     bl = np.ascontiguousarray(cone.get("bl", []), dtype=f)
     assert len(bu) == len(bl)
     k.bsize = int(cone.get("bsize", len(bu) + 1 if len(bu) else 0))
-    q = np.ascontiguousarray(cone.get("q", []), dtype=np.int32)
-    s = np.ascontiguousarray(cone.get("s", []), dtype=np.int32)
+    q = np.ascontiguousarray(cone.get("q", []), dtype=T.np_int)
+    s = np.ascontiguousarray(cone.get("s", []), dtype=T.np_int)
     pw = np.ascontiguousarray(cone.get("p", []), dtype=f)
-    cs = np.ascontiguousarray(cone.get("cs", []), dtype=np.int32)
+    cs = np.ascontiguousarray(cone.get("cs", []), dtype=T.np_int)
     holder._cone_arrays = (bu, bl, q, s, pw, cs)
     k.bu = bu.ctypes.data_as(T.fp) if len(bu) else None
     k.bl = bl.ctypes.data_as(T.fp) if len(bl) else None

@@ -348,7 +348,7 @@ struct SCS_WORK {
   int n = 0, m = 0, l = 0, device = 0;
   ScsSettings stgs;
   // deep copies (host)
-  std::vector<int> cq, cs, ccs;
+  std::vector<scs_int> cq, cs, ccs;
   std::vector<real> cbu, cbl, cpw;
   ScsCone k;
   HostCsc A, P;
@@ -440,6 +440,11 @@ static int validate_problem(const ScsData *d, const ScsCone *k, const ScsSetting
   }
   if (!d->b || !d->c) {
     printf("b or c missing\n");
+    return -1;
+  }
+  if (!fits_int32(d->A) || !fits_int32(d->P) || (long long)d->m + (long long)d->n + 1 > 2147483647LL) {
+    // only a -DDLONG caller can get here: the device indexes with 32 bits
+    printf("problem too large for 32-bit device indexing (m + n + 1 and nnz must stay below 2^31)\n");
     return -1;
   }
   if (validate_csc(d->A, d->m, d->n, false, "A") < 0) return -1;
@@ -1131,7 +1136,7 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     if (scs_update(w, w->b_orig.data(), w->c_orig.data()) != 0) throw HipError("scs_amd: scs_update failed");
     phase("vectors + b,c");
     // linear system + cones on the device
-    ScsMatrix Av = w->A.view(), Pv;
+    CscView Av = w->A.view(), Pv{nullptr, nullptr, nullptr, 0, 0};
     if (w->has_P) Pv = w->P.view();
     w->ls.init(&Av, w->has_P ? &Pv : nullptr, w->stream, &a_pattern);
     a_pattern = CsrPattern();

@@ -807,13 +807,13 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   for (int i = 0; i < k->ssize; ++i) {
     poff.push_back(off);
     pk.push_back(k->s[i]);
-    psd_kmax = std::max(psd_kmax, k->s[i]);
+    psd_kmax = std::max(psd_kmax, (int)k->s[i]);
     off += k->s[i] * (k->s[i] + 1) / 2;
   }
   for (int i = 0; i < k->cssize; ++i) { // complex PSD cones follow the real ones (cones.c:1396-1404)
     poff.push_back(off);
     pk.push_back(-2 * k->cs[i]);
-    psd_kmax = std::max(psd_kmax, 2 * k->cs[i]);
+    psd_kmax = std::max(psd_kmax, 2 * (int)k->cs[i]);
     off += k->cs[i] * k->cs[i];
   }
   n_psd = (int)poff.size();

@@ -681,7 +681,7 @@ static void host_transpose(int rows_out, int cols_out, const int *Ap, const int 
     }
 }
 
-void LinSys::init(const ScsMatrix *A_csc, const ScsMatrix *P_csc, hipStream_t s, const CsrPattern *pat) {
+void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, const CsrPattern *pat) {
   n = A_csc->n;
   m = A_csc->m;
   if (s) {
@@ -1093,9 +1093,13 @@ ScsLinSysWork *scs_init_lin_sys_work(const ScsMatrix *A, const ScsMatrix *P, con
   try {
     const int dev = selected_device(); // snapshot once: another thread may re-select concurrently
     HIP_CHECK(hipSetDevice(dev));
+    if (!fits_int32(A) || !fits_int32(P)) throw HipError("scs_amd: matrix sizes / nonzero count exceed 32-bit device indexing");
     w = new ScsLinSysWork();
     w->device = dev;
-    w->ls.init(A, P, nullptr);
+    {
+      CscArg a(A), pm(P); // aliases the caller's arrays; under -DDLONG a narrowed copy, dropped after init
+      w->ls.init(a.ptr(), pm.ptr(), nullptr);
+    }
     w->ls.b_stage.alloc((size_t)A->n + A->m);
     w->ls.s_stage.alloc((size_t)A->n);
     w->ls.set_diag_r_host(diag_r);

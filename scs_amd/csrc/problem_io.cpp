@@ -36,27 +36,29 @@ struct Reader {
     ok = ok && fread(p, sz, n, f) == n;
     return ok;
   }
-  int geti() {
+  long long getl() {
     if (int_sz == 4) {
       int32_t v = 0;
       raw(&v, 4, 1);
-      return (int)v;
+      return (long long)v;
     }
     long long v = 0;
     raw(&v, 8, 1);
-    return (int)v;
+    return v;
   }
+  int geti() { return (int)getl(); }
   real getf() {
     real v = 0;
     raw(&v, sizeof(real), 1);
     return v;
   }
-  int *ints(long n) {
+  // an index array of the file (4- or 8-byte integers, whatever wrote it) as this build's scs_int
+  scs_int *ints(long n) {
     if (n <= 0) return nullptr;
-    int *p = (int *)calloc((size_t)n, sizeof(int));
-    if (int_sz == 4) raw(p, 4, (size_t)n);
+    scs_int *p = (scs_int *)calloc((size_t)n, sizeof(scs_int));
+    if (int_sz == sizeof(scs_int)) raw(p, sizeof(scs_int), (size_t)n);
     else
-      for (long i = 0; i < n && ok; ++i) p[i] = geti();
+      for (long i = 0; i < n && ok; ++i) p[i] = (scs_int)getl();
     return p;
   }
   real *floats(long n) {

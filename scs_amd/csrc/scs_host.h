@@ -6,21 +6,56 @@ namespace scsamd {
 
 typedef scs_float real;
 
+// Internal CSC view: 32-bit indices whatever the ABI's scs_int is (the device kernels index with int; -DDLONG only
+// widens the boundary structs).  Without DLONG it aliases the caller's arrays, with DLONG CscArg narrows a copy.
+struct CscView {
+  real *x;
+  int *i, *p;
+  int m, n;
+};
+
 // owned host CSC copy (deep copy of the user's matrix; equilibrated in place)
 struct HostCsc {
   int m = 0, n = 0;
   std::vector<int> p, i;
   std::vector<real> x;
   void copy_from(const ScsMatrix *M) {
-    m = M->m;
-    n = M->n;
+    m = (int)M->m;
+    n = (int)M->n;
     const size_t nnz = (size_t)M->p[M->n];
-    p.assign(M->p, M->p + M->n + 1);
-    i.assign(M->i, M->i + nnz);
+    p.resize((size_t)n + 1);
+    i.resize(nnz);
+    for (size_t j = 0; j <= (size_t)n; ++j) p[j] = (int)M->p[j];
+    for (size_t j = 0; j < nnz; ++j) i[j] = (int)M->i[j];
     x.assign(M->x, M->x + nnz);
   }
-  ScsMatrix view() { return ScsMatrix{x.data(), i.data(), p.data(), m, n}; }
+  CscView view() { return CscView{x.data(), i.data(), p.data(), m, n}; }
 };
+
+// a caller's ScsMatrix as a CscView: aliased when scs_int is int, narrowed into an owned copy under -DDLONG
+struct CscArg {
+  HostCsc own;
+  CscView v{nullptr, nullptr, nullptr, 0, 0};
+  bool present = false;
+  explicit CscArg(const ScsMatrix *M) {
+    if (!M) return;
+    present = true;
+    if (sizeof(scs_int) == sizeof(int)) {
+      v = CscView{M->x, reinterpret_cast<int *>(M->i), reinterpret_cast<int *>(M->p), (int)M->m, (int)M->n};
+    } else {
+      own.copy_from(M);
+      v = own.view();
+    }
+  }
+  const CscView *ptr() const { return present ? &v : nullptr; }
+};
+
+// every size and index of a caller's matrix must fit the device's 32-bit indexing (only -DDLONG can violate it)
+inline bool fits_int32(const ScsMatrix *M) {
+  if (!M || !M->p) return true; // missing arrays are validate_csc's business
+  if ((long long)M->m > 2147483647LL || (long long)M->n > 2147483647LL || M->n < 0) return false;
+  return (long long)M->p[M->n] < 2147483647LL;
+}
 
 // reference include/scs_work.h:24-29 (ScsScaling)
 struct Scaling {

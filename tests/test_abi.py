@@ -29,7 +29,7 @@ def _exported(lib):
 def test_full_library_exports_every_declared_symbol():
     fns = _declared_functions()
     assert "scs_init" in fns and "scs_solve_lin_sys" in fns and "scs_amd_cone_proj_dual" in fns and "scs" in fns
-    for lib in ("libscsamd.so", "libscsamd_f32.so"):
+    for lib in ("libscsamd.so", "libscsamd_f32.so", "libscsamd_dlong.so"):
         exp = _exported(lib)
         missing = [f for f in fns if f not in exp]
         assert not missing, (lib, missing)
@@ -52,7 +52,7 @@ def test_no_gpu_is_reported_not_faked():
     assert b"amd" in lib.scs_version()
 
 
-@pytest.mark.parametrize("flag,T", [("", capi.T64), ("-DSFLOAT=1", capi.T32)])
+@pytest.mark.parametrize("flag,T", [("", capi.T64), ("-DSFLOAT=1", capi.T32), ("-DDLONG=1", capi.T64L)])
 def test_ctypes_structs_match_the_header(flag, T):
     prog = r'''
 #include <stdio.h>

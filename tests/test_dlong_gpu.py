@@ -1,0 +1,97 @@
+"""The -DDLONG flavour (libscsamd_dlong.so: 64-bit scs_int in every ABI struct, reference include/scs_types.h:13-20):
+same solve, bit for bit, as the 32-bit library on the same problem -- through scs_init/scs_solve with 64-bit index
+arrays and cone sizes, through the linear-system plugin, and through a problem file written by one flavour and read
+by the other (src/rw.c stores sizeof(scs_int) in the header)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from scs_amd import capi, problems
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dlong_solve_is_bit_identical_to_the_32_bit_library():
+    l32, l64 = capi.load("libscsamd.so"), capi.load("libscsamd_dlong.so")
+    pr = problems.random_socp(900, 2700, 9, seed=31)
+    outs = []
+    for lib in (l32, l64):
+        T = lib._scs_types
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
+        assert prob.Ai.dtype == T.np_int
+        outs.append(capi.solve(lib, prob, verbose=0, acceleration_lookback=0, max_iters=400, want_stats=True))
+    a, b = outs
+    assert a["info"]["iter"] == b["info"]["iter"] and a["info"]["status_val"] == b["info"]["status_val"]
+    assert a["stats"]["cg_iters"] == b["stats"]["cg_iters"] > 0
+    for v in ("x", "y", "s"):
+        assert np.array_equal(a[v], b[v]), v
+
+
+def test_dlong_sdp_with_box_and_anderson_acceleration_matches():
+    l32, l64 = capi.load("libscsamd.so"), capi.load("libscsamd_dlong.so")
+    pr = problems.random_sdp(120, 6, 12, 21, 6, seed=5)
+    outs = []
+    for lib in (l32, l64):
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=lib._scs_types)
+        outs.append(capi.solve(lib, prob, verbose=0, acceleration_lookback=10, max_iters=300))
+    a, b = outs
+    assert a["info"]["iter"] == b["info"]["iter"]
+    assert a["info"]["accepted_accel_steps"] == b["info"]["accepted_accel_steps"]
+    for v in ("x", "y", "s"):
+        assert np.array_equal(a[v], b[v]), v
+
+
+def test_dlong_linsys_plugin_boundary():
+    l32, l64 = capi.load("libscsamd.so"), capi.load("libscsamd_dlong.so")
+    pr = problems.random_socp(500, 1500, 7, seed=8)
+    rng = np.random.default_rng(0)
+    n, m = 500, 1500
+    dr = np.concatenate([np.full(n, 1e-6), rng.uniform(0.1, 10.0, m)])
+    b0 = rng.standard_normal(n + m)
+    res = []
+    for lib in (l32, l64):
+        T = lib._scs_types
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
+        w = lib.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
+        assert w
+        b = b0.copy()
+        assert lib.scs_solve_lin_sys(w, b.ctypes.data_as(T.fp), None, 1e-10) == 0
+        lib.scs_free_lin_sys_work(w)
+        res.append(b)
+    assert np.array_equal(res[0], res[1])
+    assert np.abs(res[0]).max() > 0
+
+
+def test_problem_files_cross_the_two_integer_widths(tmp_path):
+    l32, l64 = capi.load("libscsamd.so"), capi.load("libscsamd_dlong.so")
+    pr = problems.random_socp(200, 600, 5, seed=2)
+    sols = {}
+    for tag, lib in (("i32", l32), ("i64", l64)):
+        T = lib._scs_types
+        prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
+        fn = str(tmp_path / f"prob_{tag}.bin").encode()
+        st = capi.default_settings(lib, verbose=0, acceleration_lookback=0, max_iters=200, write_data_filename=fn)
+        sols[tag] = capi.solve(lib, prob, settings=st)
+        assert os.path.getsize(fn) > 1000
+    assert np.array_equal(sols["i32"]["x"], sols["i64"]["x"])
+    # the 64-bit file is larger (every index doubles) and each library reads the OTHER's file and solves it to the same x
+    s32, s64 = (os.path.getsize(tmp_path / f"prob_{t}.bin") for t in ("i32", "i64"))
+    assert s64 > s32
+    for reader, fn in ((l32, "prob_i64.bin"), (l64, "prob_i32.bin")):
+        T = reader._scs_types
+        PD, PK, PS = C.POINTER(T.ScsData), C.POINTER(T.ScsCone), C.POINTER(T.ScsSettings)
+        reader.scs_amd_read_data.restype = T.scs_int
+        reader.scs_amd_read_data.argtypes = [C.c_char_p, C.POINTER(PD), C.POINTER(PK), C.POINTER(PS)]
+        reader.scs_amd_free_data.argtypes = [PD, PK, PS]
+        d, k, st = PD(), PK(), PS()
+        assert reader.scs_amd_read_data(str(tmp_path / fn).encode(), C.byref(d), C.byref(k), C.byref(st)) == 0
+        assert d.contents.n == 200 and d.contents.m == 600 and k.contents.qsize == len(pr["cone"]["q"])
+        st.contents.write_data_filename = None
+        x, y, sv = np.zeros(200), np.zeros(600), np.zeros(600)
+        sol = T.ScsSolution(x.ctypes.data_as(T.fp), y.ctypes.data_as(T.fp), sv.ctypes.data_as(T.fp))
+        info = T.ScsInfo()
+        reader.scs(d, k, st, C.byref(sol), C.byref(info))
+        reader.scs_amd_free_data(d, k, st)
+        assert np.array_equal(x, sols["i32"]["x"]), fn
