@@ -17,7 +17,7 @@
 // kernel, and the sum is reproducible bit for bit.  Inside a unit the entries are stored by
 // ascending column bucket; all waves are resident at once and start together, so at any moment
 // the whole chip gathers from one window of x that moves upwards and stays in every XCD's L2
-// (measured 91 % L2 hits on the gathers, profiles/r2_g2_lab_pmc.md).  Units are balanced by
+// (measured 91 % L2 hits on the gathers, profiles/r2_g2_lab.md section 7).  Units are balanced by
 // nonzeros (about 8 waves per CU: fewer, fatter waves measured faster than many thin ones).
 // Summation order inside a row is column-bucket order with row-major ties (rounding-level
 // difference from the reference's index order).
