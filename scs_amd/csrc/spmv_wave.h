@@ -1,4 +1,4 @@
-// spmv_wave.h -- "wave-owned rows" CSR product for gather vectors that do not fit a 4 MB XCD L2
+// spmv_wave.h -- "wave-owned rows" CSR product for matrices from a million nonzeros on
 // (same results and epilogues as csr_stream_kernel in spmv.h; replaces round 1's column-sliced
 // kernel).  Replaces SCS(accum_by_atrans), reference linsys/scs_matrix.c:161-186.
 //
@@ -125,13 +125,13 @@ struct WaveRowsDev {
     while ((1ll << b) < cols) ++b;
     return b;
   }
-  // worth it only when the gathered vector overflows an XCD's L2 (below that csr_stream's gathers
-  // are L2 hits anyway) and there are enough nonzeros to fill the chip
+  // From a million nonzeros on: measured us per CG iteration, this kernel vs csr_stream (fp64, 10 nonzeros per
+  // column): nnz 5e5 23.5 / 23.5, 1e6 30.0 / 32.7, 1.5e6 34.8 / 38.5, 2e6 39.3 / 43.3, 4e6 61.3 / 76.5 -- no
+  // barriers and no product staging pay even while the gathered vector still fits an XCD's L2
   static bool wanted(int cols, const int *hptr, int rows) {
     if (col_bits(cols) > 26) return false; // packed word: column bits + at least 6 row bits
     if (const char *e = getenv("SCS_AMD_WAVEROWS")) return atoi(e) != 0; // tests force either path
-    if ((size_t)cols * sizeof(real) <= (size_t)3 << 20) return false;
-    return (long long)hptr[rows] >= 4000000LL;
+    return (long long)hptr[rows] >= 1000000LL;
   }
   void build(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval, hipStream_t st) {
     rows = rows_;
