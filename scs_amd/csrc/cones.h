@@ -35,7 +35,6 @@ struct ConeDev {
   // PSD cones
   int n_psd = 0, psd_kmax = 0, psd_lds_kmax = 0;
   DevBuf<int> psd_off, psd_k;
-  DevBuf<real> psd_work;    // unused (kept for the kernel signature)
   BigPsd *psd_big = nullptr; // blocks of order > PSD_LDS_KMAX: chip-wide Jacobi steps
   DevBuf<real> psd_vprev;   // per block: eigenbasis of the previous projection (warm start; k <= 72)
   long long psd_calls = 0;  // projections since the last cold start

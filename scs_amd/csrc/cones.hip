@@ -831,8 +831,10 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
     psd_big->init(pk, PSD_LDS_KMAX, stream);
   }
   psd_calls = 0;
-  if (n_psd && psd_kmax <= PSD_WARM_KMAX && !getenv("SCS_AMD_PSD_COLD"))
-    psd_vprev.alloc((size_t)n_psd * ((psd_kmax + 1) & ~1) * (((psd_kmax + 1) & ~1) | 1));
+  // warm start of the LDS kernel: sized and gated by the largest block that kernel handles (blocks beyond the LDS path
+  // carry their own basis in psd_big, and must not switch the small blocks' warm start off)
+  if (n_psd && psd_lds_kmax >= 2 && psd_lds_kmax <= PSD_WARM_KMAX && !getenv("SCS_AMD_PSD_COLD"))
+    psd_vprev.alloc((size_t)n_psd * ((psd_lds_kmax + 1) & ~1) * (((psd_lds_kmax + 1) & ~1) | 1));
   ep = k->ep;
   ed = k->ed;
   psize = k->psize;
@@ -885,7 +887,7 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_psd_jacobi),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
-                       psd_work.p, psd_kmax, lds_kmax, status.p, psd_vprev.p, warm);
+                       (real *)nullptr, lds_kmax, lds_kmax, status.p, psd_vprev.p, warm);
     if (psd_big) psd_big->project(cw, psd_off.p, psd_k.p, status.p, stream);
   }
   proj_exp_pow(cw);

@@ -1,314 +1,324 @@
-// cones_exp_pow.h -- exponential and power cone projections, one lane per 3-row cone.
+// cones_exp_pow.h -- exponential / dual exponential / power / dual power cones (3 rows each) for CDNA4.
 //
-// SURVEY.md section 8(f) item 3 (the first "next" row after the hot path): these cones
-// appear in CVXPY-generated problems and are embarrassingly parallel (the reference
-// itself OpenMPs the exponential loop, src/cones.c:1407-1412).  What is computed follows
-//   exponential cone: src/exp_cone.c:373-441 `proj_pd_exp_cone` -- Friberg (2021),
-//       "Projection onto the exponential cone: a univariate root-finding problem":
-//       heuristic projections on primal/polar (:160-207), optimality shortcut (:395-411),
-//       bracket for the root of h (:249-317), damped Newton with bisection fallback
-//       (:66-157), conversion of the root to the primal/polar point (:320-367);
-//   power cone: src/cones.c:1284-1335 `proj_power_cone` (Newton on r, <= 20 steps) and
-//       the Moreau form for dual power cones (:1427-1441).
-// All scalar work is done in the build's scs_float, with the same constants and the same
-// branch order, so results match the reference to rounding.
+// What must come out is what the reference returns (src/exp_cone.c:373-441 `proj_pd_exp_cone`,
+// src/cones.c:1290-1335 `proj_power_cone`, Moreau form for the dual power cone :1427-1441), to rounding.
+// How it is computed here is laid out for 64-wide wavefronts instead of one scalar cone at a time:
+//
+//  * a 256-lane workgroup stages 256 consecutive triples (768 values) through LDS with unit-stride global loads and
+//    stores; each lane then owns one triple in registers;
+//  * control flow is wave-uniform: every lane evaluates the cheap closed-form candidates, the wave votes
+//    (`wave_any`) on whether anybody needs the root search, and the search itself is a predicated loop -- lanes
+//    that are finished freeze their state, the loop leaves when the whole wave is finished -- so no lane ever
+//    waits in a divergent branch of its neighbour;
+//  * the exponential-cone root search is a bracketed Newton iteration whose bracket only moves through
+//    min / max selects (no data-dependent exits, no separate bisection routine).
+//
+// Exponential cone, the geometry used (u = v[0], w = v[1], t = v[2]; K = cl{w > 0, w e^(u/w) <= t}):
+// the boundary of K is swept by the rays g(rho) = (rho, 1, e^rho), and the outward normal at g(rho) is
+// n(rho) = (1, 1 - rho, -e^-rho), which sweeps the boundary of the polar cone.  A point outside both cones
+// decomposes as v = a g(rho) + b n(rho) with a, b > 0 (Moreau); the first two rows give
+//     a = ((rho - 1) u + w) / q,   b = (u - rho w) / q,   q = rho^2 - rho + 1,
+// and the third row is one equation in rho alone,
+//     F(rho) = ((rho - 1) u + w) e^rho - (u - rho w) e^-rho - q t = 0,
+// increasing on the interval where a, b > 0 (Friberg 2021 derives the same equation; the reference's h(rho)).
+// The projection onto K is a g(rho), onto the polar cone b n(rho).
+//
+// Behaviour that belongs to the reference's observable results and is therefore kept (not its code):
+//  * two closed-form candidates per cone -- the point's own "snap" onto K (keep (u, w), lift t to the surface)
+//    or onto the trivial face, likewise for the polar cone -- are returned as they are when (u, w) <= 0, when
+//    one of them is within 1e-8 of v, or when the pair already is a Moreau decomposition to 1e-8
+//    (exp_cone.c:395-411): points that close to the surface are NOT refined by the root search;
+//  * the root's point replaces a candidate only if it is at least as close to v (exp_cone.c:421-437), and
+//    rays with e^(+-rho) >= 1e15 are discarded (exp_cone.c:320-367);
+//  * the power cone stops its Newton iteration on r at |f| < 1e-9 or after 20 steps (cones.c:1309-1330): the
+//    returned point carries that residual, so the iteration is followed step for step -- wave-wide, lanes
+//    freezing at their own stopping step.
 #pragma once
+#ifndef SCSAMD_EXPPOW_HOST_CHECK
 #include "common.h"
+#endif
 
 namespace scsamd {
 
+#if defined(__HIPCC__) || defined(SCSAMD_EXPPOW_HOST_CHECK)
+#ifdef SCSAMD_EXPPOW_HOST_CHECK // tests/host_check_exp_pow.cpp: the same arithmetic, one lane at a time, on the host
+#define XP_DEV inline
+#define XP_ANY(pred) (pred)
+#else
+#define XP_DEV __device__ __forceinline__
+#define XP_ANY(pred) (__any(pred) != 0)
+#endif
+typedef scs_float xreal;
+
+struct Triple {
+  xreal u, w, t;
+};
+
+namespace xp {
+constexpr xreal SNAP_TOL = (xreal)1e-8;   // candidates this close are final (exp_cone.c:379)
+constexpr xreal RAY_CUTOFF = (xreal)1e15; // e^(+-rho) beyond this: the ray is not used (exp_cone.c:36)
+constexpr xreal FAR = (xreal)1e30;        // "no candidate" distance
+constexpr int EXPAND_TRIPS = 11;          // open end of the search interval: probe at 1, 2, 4, ... 1024 from the closed end
+constexpr int NEWTON_TRIPS = sizeof(xreal) == 8 ? 80 : 40; // upper bound; a wave leaves as soon as all its lanes have converged
+XP_DEV xreal sel(bool c, xreal a, xreal b) { return c ? a : b; }
+XP_DEV xreal vmin(xreal a, xreal b) { return a < b ? a : b; }
+XP_DEV xreal vmax(xreal a, xreal b) { return a > b ? a : b; }
+XP_DEV xreal vabs(xreal a) { return a < 0 ? -a : a; }
+XP_DEV xreal sq(xreal a) { return a * a; }
+XP_DEV xreal dist2(const Triple &a, const Triple &b) { return sq(a.u - b.u) + sq(a.w - b.w) + sq(a.t - b.t); }
+XP_DEV xreal rho_cap() { return sizeof(xreal) == 8 ? (xreal)700 : (xreal)85; }
+
+// F(rho) and F'(rho): one exponential, one reciprocal
+XP_DEV void eval_F(const Triple &v, xreal rho, xreal &F, xreal &dF) {
+  const xreal e = exp(rho), ei = (xreal)1 / e;
+  const xreal ga = (rho - 1) * v.u + v.w; // q a
+  const xreal gb = v.u - rho * v.w;       // q b
+  F = ga * e - gb * ei - (rho * (rho - 1) + 1) * v.t;
+  dF = (ga + v.u) * e + (gb + v.w) * ei - (2 * rho - 1) * v.t;
+}
+
+// closed-form candidate in K: the trivial face (min(u,0), 0, max(t,0)), or -- if closer -- v itself with t lifted to
+// the surface w e^(u/w) (exp_cone.c:160-182)
+XP_DEV xreal snap_primal(const Triple &v, Triple &p) {
+  p.u = vmin(v.u, (xreal)0);
+  p.w = 0;
+  p.t = vmax(v.t, (xreal)0);
+  xreal d = dist2(v, p);
+  const bool up = v.w > (xreal)0;
+  const xreal ws = sel(up, v.w, (xreal)1);
+  const xreal lift = vmax(v.t, ws * exp(v.u / ws));
+  const bool take = up && sq(lift - v.t) < d;
+  p.u = sel(take, v.u, p.u);
+  p.w = sel(take, v.w, p.w);
+  p.t = sel(take, lift, p.t);
+  return sel(take, sq(lift - v.t), d);
+}
+// closed-form candidate in the polar cone: (0, min(w,0), min(t,0)), or v with t pushed down to -u e^(w/u - 1)
+// (exp_cone.c:185-207)
+XP_DEV xreal snap_polar(const Triple &v, Triple &d3) {
+  d3.u = 0;
+  d3.w = vmin(v.w, (xreal)0);
+  d3.t = vmin(v.t, (xreal)0);
+  xreal d = dist2(v, d3);
+  const bool up = v.u > (xreal)0;
+  const xreal us = sel(up, v.u, (xreal)1);
+  const xreal sink = vmin(v.t, -us * exp(v.w / us - (xreal)1));
+  const bool take = up && sq(v.t - sink) < d;
+  d3.u = sel(take, v.u, d3.u);
+  d3.w = sel(take, v.w, d3.w);
+  d3.t = sel(take, sink, d3.t);
+  return sel(take, sq(v.t - sink), d);
+}
+
+// Root of F on the interval where both Moreau coefficients are positive.  `live`: this lane takes part (the others
+// run along with frozen state).  The interval: a > 0 bounds rho from below (u > 0) or above (u < 0) at 1 - w/u, b > 0
+// bounds it from above (w > 0) or below (w < 0) at u/w; whenever (u, w) is not <= 0 at least one end is finite, F < 0
+// at a finite lower end and F > 0 at a finite upper end.  An open end is closed by probing at doubling distances.
+XP_DEV xreal root_of_F(const Triple &v, bool live) {
+  const xreal cap = rho_cap();
+  const bool up = v.u > 0, un = v.u < 0, wp = v.w > 0, wn = v.w < 0;
+  const xreal e1 = (xreal)1 - v.w / sel(up || un, v.u, (xreal)1); // end from a = 0
+  const xreal e2 = v.u / sel(wp || wn, v.w, (xreal)1);            // end from b = 0
+  xreal lo = vmax(sel(up, e1, -cap), sel(wn, e2, -cap));
+  xreal hi = vmin(sel(un, e1, cap), sel(wp, e2, cap));
+  lo = vmin(vmax(lo, -cap), cap);
+  hi = vmax(vmin(hi, cap), -cap);
+  const bool open_hi = !(un || wp), open_lo = !(up || wn);
+  { // close the open end (at most one is open)
+    const xreal anchor = sel(open_hi, lo, hi), dir = sel(open_hi, (xreal)1, (xreal)-1);
+    bool grow = live && (open_hi || open_lo);
+    xreal reach = 1;
+    xreal near = anchor; // the bracket end on the anchor's side
+    for (int k = 0; k < EXPAND_TRIPS; ++k) {
+      if (!XP_ANY(grow)) break;
+      const xreal probe = vmax(vmin(anchor + dir * reach, cap), -cap);
+      xreal F, dF;
+      eval_F(v, probe, F, dF);
+      const bool beyond = dir > 0 ? !(F < 0) : F < 0; // the probe is past the root: it closes the bracket
+      if (grow) {
+        if (beyond) {
+          if (dir > 0) { lo = near; hi = probe; } else { hi = near; lo = probe; }
+          grow = false;
+        } else {
+          near = probe;
+          reach *= 2;
+        }
+      }
+    }
+    if (grow) { // never crossed within reach: search what is left up to the cap
+      if (dir > 0) { lo = near; hi = cap; } else { hi = near; lo = -cap; }
+    }
+  }
+  const bool proper = lo < hi; // degenerate interval: the root is the end itself
+  xreal x = sel(proper, (xreal)0.5 * (lo + hi), lo), last = hi - lo;
+  bool run = live && proper;
+  const xreal ulp = sizeof(xreal) == 8 ? (xreal)4.5e-16 : (xreal)2.4e-7;
+  for (int k = 0; k < NEWTON_TRIPS; ++k) {
+    if (!XP_ANY(run)) break;
+    xreal F, dF;
+    eval_F(v, x, F, dF);
+    const bool below = F < 0;
+    const xreal nlo = sel(below, x, lo), nhi = sel(below, hi, x);
+    const xreal xn = x - F / dF;
+    const xreal mid = (xreal)0.5 * (nlo + nhi);
+    // the Newton point is taken when it lands strictly inside the bracket and at least halves the previous move
+    const bool newton_ok = dF > 0 && xn > nlo && xn < nhi && vabs(xn - x) <= (xreal)0.5 * last;
+    const xreal nx = sel(newton_ok, xn, mid);
+    const bool settled = F == 0 || nx == x || nhi - nlo <= ulp * vmax((xreal)1, vabs(x));
+    if (run) {
+      lo = nlo;
+      hi = nhi;
+      if (!settled) {
+        last = vabs(nx - x);
+        x = nx;
+      }
+      run = !settled;
+    }
+  }
+  return x;
+}
+
+// the points the root's rays give: in K, a g(rho); in the polar cone, b n(rho)
+XP_DEV xreal ray_primal(const Triple &v, xreal rho, Triple &p) {
+  const xreal e = exp(rho), ga = (rho - 1) * v.u + v.w, q = rho * (rho - 1) + 1;
+  const bool ok = ga > 0 && vabs(e) < RAY_CUTOFF;
+  const xreal a = ga / q;
+  p.u = a * rho;
+  p.w = a;
+  p.t = a * e;
+  return sel(ok, dist2(p, v), FAR);
+}
+XP_DEV xreal ray_polar(const Triple &v, xreal rho, Triple &d3) {
+  const xreal ei = exp(-rho), gb = v.u - rho * v.w, q = rho * (rho - 1) + 1;
+  const bool ok = gb > 0 && vabs(ei) < RAY_CUTOFF;
+  const xreal b = gb / q;
+  d3.u = b;
+  d3.w = b * ((xreal)1 - rho);
+  d3.t = -b * ei;
+  return sel(ok, dist2(v, d3), FAR);
+}
+
+// `is_exp`: this lane holds an exponential-cone triple; dual = project onto the dual cone K* = -(polar cone)
+XP_DEV Triple project_exp(Triple v, bool is_exp, bool dual) {
+  if (dual) { v.u = -v.u; v.w = -v.w; v.t = -v.t; } // Proj_K*(v) = -Proj_polar(-v)
+  Triple P, D;
+  const xreal dP = snap_primal(v, P), dD = snap_polar(v, D);
+  const xreal gap = vmax(vmax(vabs(P.u + D.u - v.u), vabs(P.w + D.w - v.w)), vabs(P.t + D.t - v.t));
+  const bool final_snap = (v.u <= 0 && v.w <= 0) || vmin(dP, dD) <= SNAP_TOL * SNAP_TOL ||
+                          (gap <= SNAP_TOL && P.u * D.u + P.w * D.w + P.t * D.t <= SNAP_TOL);
+  const bool search = is_exp && !final_snap;
+  if (XP_ANY(search)) {
+    const xreal rho = root_of_F(v, search);
+    Triple R;
+    if (XP_ANY(search && !dual)) {
+      const xreal dR = ray_primal(v, rho, R);
+      if (search && !dual && dR <= dP) P = R;
+    }
+    if (XP_ANY(search && dual)) {
+      const xreal dR = ray_polar(v, rho, R);
+      if (search && dual && dR <= dD) D = R;
+    }
+  }
+  Triple out;
+  out.u = dual ? -D.u : P.u;
+  out.w = dual ? -D.w : P.w;
+  out.t = dual ? -D.t : P.t;
+  return out;
+}
+
+// ---- power cone {x^a y^(1-a) >= |z|, x, y >= 0} -------------------------------------------------------------------
+constexpr xreal POW_TOL = (xreal)1e-9; // membership slack and Newton stopping residual (cones.c:1291)
+constexpr int POW_TRIPS = 20;
+// coordinate on the optimality curve for a trial |z| = r (cones.c:1284-1288)
+XP_DEV xreal pow_coord(xreal r, xreal c0, xreal r0, xreal a) {
+  return vmax((xreal)0.5 * (c0 + sqrt(c0 * c0 + 4 * a * (r0 - r) * r)), (xreal)1e-12);
+}
+XP_DEV Triple project_pow(const Triple &v, xreal a, bool live) {
+  const xreal x0 = v.u, y0 = v.w, r0 = vabs(v.t), a1 = (xreal)1 - a;
+  // inside the cone / inside the polar cone: decided on clamped operands so that idle lanes never see pow(negative)
+  const bool pos = x0 >= 0 && y0 >= 0, neg = x0 <= 0 && y0 <= 0;
+  const xreal ax = vabs(x0), ay = vabs(y0);
+  const xreal mono = pow(ax, a) * pow(ay, a1);
+  const bool inside = pos && POW_TOL + mono >= r0;
+  const bool in_polar = !inside && neg && POW_TOL + mono >= r0 * pow(a, a) * pow(a1, a1);
+  bool run = live && !inside && !in_polar;
+  xreal x = 0, y = 0, r = (xreal)0.5 * r0;
+  for (int k = 0; k < POW_TRIPS; ++k) {
+    if (!XP_ANY(run)) break;
+    const xreal xs = pow_coord(r, x0, r0, a), ys = pow_coord(r, y0, r0, a1);
+    const xreal xa = pow(xs, a), yb = pow(ys, a1);
+    const xreal f = xa * yb - r;
+    const xreal slope = (r0 - 2 * r);
+    const xreal dx = a * slope / (2 * xs - x0), dy = a1 * slope / (2 * ys - y0);
+    const xreal df = xa * yb * (a * dx / xs + a1 * dy / ys) - (xreal)1;
+    const xreal rn = vmin(vmax(r - f / df, (xreal)0), r0);
+    if (run) {
+      x = xs;
+      y = ys;
+      const bool stop = vabs(f) < POW_TOL;
+      r = sel(stop, r, rn);
+      run = !stop;
+    }
+  }
+  Triple out;
+  out.u = inside ? v.u : (in_polar ? (xreal)0 : x);
+  out.w = inside ? v.w : (in_polar ? (xreal)0 : y);
+  out.t = inside ? v.t : (in_polar ? (xreal)0 : (v.t < 0 ? -r : r));
+  return out;
+}
+} // namespace xp
+
 #ifdef __HIPCC__
-typedef scs_float ereal;
-
-#define EXPC_INF ((ereal)1e15)
-
-__device__ __forceinline__ bool ec_finite(ereal x) { return absval(x) < EXPC_INF; }
-__device__ __forceinline__ ereal ec_max(ereal a, ereal b) { return a > b ? a : b; }
-__device__ __forceinline__ ereal ec_min(ereal a, ereal b) { return a < b ? a : b; }
-__device__ __forceinline__ ereal ec_clip(ereal x, ereal l, ereal u) { return ec_max(l, ec_min(u, x)); }
-__device__ __forceinline__ ereal ec_safediv_pos(ereal x, ereal y) { return y < (ereal)1e-18 ? x / (ereal)1e-18 : x / y; }
-__device__ __forceinline__ ereal ec_dist_sq(const ereal *a, const ereal *b) {
-  const ereal d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
-  return d0 * d0 + d1 * d1 + d2 * d2;
-}
-
-// h(rho) and h'(rho), exp_cone.c:41-64
-__device__ __forceinline__ void ec_h(const ereal *v0, ereal rho, ereal *f, ereal *df) {
-  const ereal t0 = v0[2], s0 = v0[1], r0 = v0[0];
-  const ereal er = exp(rho), enr = (ereal)1.0 / er;
-  *f = ((rho - 1) * r0 + s0) * er - (r0 - rho * s0) * enr - (rho * (rho - 1) + 1) * t0;
-  if (df) *df = (rho * r0 + s0) * er + (r0 - (rho - 1) * s0) * enr - (2 * rho - 1) * t0;
-}
-
-__device__ ereal ec_bisect(const ereal *v0, ereal xl, ereal xu, ereal x) { // exp_cone.c:67-98
-  ereal x_plus = x, f;
-  for (int i = 0; i < 40; ++i) {
-    ec_h(v0, x, &f, nullptr);
-    if (f < (ereal)0.0) xl = x;
-    else xu = x;
-    x_plus = (ereal)0.5 * (xl + xu);
-    if (absval(x_plus - x) <= (ereal)1e-12 * ec_max((ereal)1.0, absval(x_plus)) || x_plus == xl || x_plus == xu) break;
-    x = x_plus;
-  }
-  return x_plus;
-}
-
-__device__ ereal ec_newton(const ereal *v0, ereal xl, ereal xu, ereal x) { // exp_cone.c:101-157
-  const ereal EPS = (ereal)1e-15, DFTOL = (ereal)1e-13, LODAMP = (ereal)0.05, HIDAMP = (ereal)0.95;
-  ereal x_plus, f, df;
-  int i;
-  for (i = 0; i < 20; ++i) {
-    ec_h(v0, x, &f, &df);
-    if (absval(f) <= EPS) break;
-    if (f < (ereal)0.0) xl = x;
-    else xu = x;
-    if (xu <= xl) {
-      xu = (ereal)0.5 * (xu + xl);
-      xl = xu;
-      break;
-    }
-    if (!ec_finite(f) || df < DFTOL) break;
-    x_plus = x - f / df;
-    if (absval(x_plus - x) <= EPS * ec_max((ereal)1.0, absval(x_plus))) break;
-    if (x_plus >= xu) x = ec_min(LODAMP * x + HIDAMP * xu, xu);
-    else if (x_plus <= xl) x = ec_max(LODAMP * x + HIDAMP * xl, xl);
-    else x = x_plus;
-  }
-  if (i < 20) return ec_clip(x, xl, xu);
-  return ec_bisect(v0, xl, xu, x);
-}
-
-__device__ ereal ec_heur_primal(const ereal *v0, ereal *vp) { // exp_cone.c:160-182
-  const ereal t0 = v0[2], s0 = v0[1], r0 = v0[0];
-  vp[2] = ec_max(t0, (ereal)0.0);
-  vp[1] = 0;
-  vp[0] = ec_min(r0, (ereal)0.0);
-  ereal d = ec_dist_sq(v0, vp);
-  if (s0 > (ereal)0.0) {
-    const ereal tp = ec_max(t0, s0 * exp(r0 / s0));
-    const ereal nd = (tp - t0) * (tp - t0);
-    if (nd < d) {
-      vp[2] = tp;
-      vp[1] = s0;
-      vp[0] = r0;
-      d = nd;
-    }
-  }
-  return d;
-}
-__device__ ereal ec_heur_polar(const ereal *v0, ereal *vd) { // exp_cone.c:185-207
-  const ereal t0 = v0[2], s0 = v0[1], r0 = v0[0];
-  vd[2] = ec_min(t0, (ereal)0.0);
-  vd[1] = ec_min(s0, (ereal)0.0);
-  vd[0] = 0;
-  ereal d = ec_dist_sq(v0, vd);
-  if (r0 > (ereal)0.0) {
-    const ereal td = ec_min(t0, -r0 * exp(s0 / r0 - (ereal)1.0));
-    const ereal nd = (t0 - td) * (t0 - td);
-    if (nd < d) {
-      vd[2] = td;
-      vd[1] = s0;
-      vd[0] = r0;
-      d = nd;
-    }
-  }
-  return d;
-}
-
-__device__ ereal ec_ppsi(const ereal *v0) { // exp_cone.c:209-220
-  const ereal s0 = v0[1], r0 = v0[0];
-  const ereal q = sqrt(r0 * r0 + s0 * s0 - r0 * s0);
-  const ereal psi = r0 > s0 ? (r0 - s0 + q) / r0 : -s0 / (r0 - s0 - q);
-  return ((psi - (ereal)1.0) * r0 + s0) / (psi * (psi - (ereal)1.0) + (ereal)1.0);
-}
-__device__ ereal ec_pomega(ereal rho) { // :222-229
-  ereal v = exp(rho) / (rho * (rho - (ereal)1.0) + (ereal)1.0);
-  if (rho < (ereal)2.0) v = ec_min(v, exp((ereal)2.0) / (ereal)3.0);
-  return v;
-}
-__device__ ereal ec_dpsi(const ereal *v0) { // :231-242
-  const ereal s0 = v0[1], r0 = v0[0];
-  const ereal q = sqrt(r0 * r0 + s0 * s0 - r0 * s0);
-  const ereal psi = s0 > r0 ? (r0 - q) / s0 : (r0 - s0) / (r0 + q);
-  return (r0 - psi * s0) / (psi * (psi - (ereal)1.0) + (ereal)1.0);
-}
-__device__ ereal ec_domega(ereal rho) { // :244-251
-  ereal v = -exp(-rho) / (rho * (rho - (ereal)1.0) + (ereal)1.0);
-  if (rho > (ereal)-1.0) v = ec_max(v, -exp((ereal)1.0) / (ereal)3.0);
-  return v;
-}
-
-__device__ void ec_bracket(const ereal *v0, ereal pd, ereal dd, ereal *lo, ereal *up) { // exp_cone.c:254-317
-  const ereal t0 = v0[2], s0 = v0[1], r0 = v0[0];
-  ereal baselow = -EXPC_INF, baseupr = EXPC_INF, low = -EXPC_INF, upr = EXPC_INF;
-  const ereal ms = ec_min(s0, (ereal)0.0), mr = ec_min(r0, (ereal)0.0);
-  const ereal Dp = sqrt(ec_max(pd - ms * ms, (ereal)0.0)), Dd = sqrt(ec_max(dd - mr * mr, (ereal)0.0));
-  if (t0 > (ereal)0.0) low = ec_max(low, log(t0 / ec_ppsi(v0)));
-  else if (t0 < (ereal)0.0) upr = ec_min(upr, -log(-t0 / ec_dpsi(v0)));
-  if (r0 > (ereal)0.0) {
-    baselow = (ereal)1.0 - s0 / r0;
-    low = ec_max(low, baselow);
-    const ereal tpu = ec_max((ereal)1e-12, ec_min(Dd, Dp + t0));
-    const ereal val = r0 * ec_pomega(low);
-    const ereal sgn = val < 0 ? (ereal)-1 : (ereal)1;
-    upr = ec_min(upr, ec_max(low, baselow + ec_safediv_pos(tpu, absval(val)) * sgn));
-  }
-  if (s0 > (ereal)0.0) {
-    baseupr = r0 / s0;
-    upr = ec_min(upr, baseupr);
-    const ereal tdl = -ec_max((ereal)1e-12, ec_min(Dp, Dd - t0));
-    const ereal val = s0 * ec_domega(upr);
-    const ereal sgn = val < 0 ? (ereal)-1 : (ereal)1;
-    low = ec_max(low, ec_min(upr, baseupr - ec_safediv_pos(tdl, absval(val)) * sgn));
-  }
-  low = ec_clip(ec_min(low, upr), baselow, baseupr);
-  upr = ec_clip(ec_max(low, upr), baselow, baseupr);
-  if (low != upr) {
-    ereal fl, fu;
-    ec_h(v0, low, &fl, nullptr);
-    ec_h(v0, upr, &fu, nullptr);
-    if (fl * fu > (ereal)0.0) {
-      if (absval(fl) < absval(fu)) upr = low;
-      else low = upr;
-    }
-  }
-  *lo = low;
-  *up = upr;
-}
-
-__device__ ereal ec_sol_primal(const ereal *v0, ereal rho, ereal *vp) { // exp_cone.c:320-342
-  const ereal lin = (rho - (ereal)1.0) * v0[0] + v0[1], er = exp(rho);
-  if (lin > (ereal)0.0 && ec_finite(er)) {
-    const ereal q = rho * (rho - (ereal)1.0) + (ereal)1.0;
-    vp[2] = er * lin / q;
-    vp[1] = lin / q;
-    vp[0] = rho * lin / q;
-    return ec_dist_sq(vp, v0);
-  }
-  vp[2] = EXPC_INF;
-  vp[1] = 0;
-  vp[0] = 0;
-  return EXPC_INF;
-}
-__device__ ereal ec_sol_polar(const ereal *v0, ereal rho, ereal *vd) { // exp_cone.c:345-367
-  const ereal lin = v0[0] - rho * v0[1], er = exp(-rho);
-  if (lin > (ereal)0.0 && ec_finite(er)) {
-    const ereal q = rho * (rho - (ereal)1.0) + (ereal)1.0;
-    vd[2] = -er * lin / q;
-    vd[1] = ((ereal)1.0 - rho) * lin / q;
-    vd[0] = lin / q;
-    return ec_dist_sq(v0, vd);
-  }
-  vd[2] = -EXPC_INF;
-  vd[1] = 0;
-  vd[0] = 0;
-  return EXPC_INF;
-}
-
-// in-place projection of one triple onto the exponential cone (primal != 0) or its dual
-__device__ void proj_exp_cone_triple(ereal *v0, int primal) { // exp_cone.c:373-441
-  const ereal TOL = (ereal)1e-8;
-  ereal vp[3], vd[3], vh[3], xl, xh;
-  if (!primal) {
-    v0[0] = -v0[0];
-    v0[1] = -v0[1];
-    v0[2] = -v0[2];
-  }
-  ereal pd = ec_heur_primal(v0, vp), dd = ec_heur_polar(v0, vd);
-  ereal err = absval(vp[0] + vd[0] - v0[0]);
-  err = ec_max(err, absval(vp[1] + vd[1] - v0[1]));
-  err = ec_max(err, absval(vp[2] + vd[2] - v0[2]));
-  bool opt = v0[1] <= (ereal)0.0 && v0[0] <= (ereal)0.0;
-  opt = opt || ec_min(pd, dd) <= TOL * TOL;
-  opt = opt || (err <= TOL && (vp[0] * vd[0] + vp[1] * vd[1] + vp[2] * vd[2]) <= TOL);
-  if (!opt) {
-    ec_bracket(v0, pd, dd, &xl, &xh);
-    const ereal rho = ec_newton(v0, xl, xh, (ereal)0.5 * (xl + xh));
-    if (primal) {
-      const ereal dh = ec_sol_primal(v0, rho, vh);
-      if (dh <= pd) {
-        vp[0] = vh[0];
-        vp[1] = vh[1];
-        vp[2] = vh[2];
-      }
-    } else {
-      const ereal dh = ec_sol_polar(v0, rho, vh);
-      if (dh <= dd) {
-        vd[0] = vh[0];
-        vd[1] = vh[1];
-        vd[2] = vh[2];
-      }
-    }
-  }
-  if (primal) {
-    v0[0] = vp[0];
-    v0[1] = vp[1];
-    v0[2] = vp[2];
-  } else { // polar -> dual
-    v0[0] = -vd[0];
-    v0[1] = -vd[1];
-    v0[2] = -vd[2];
-  }
-}
-
-// ---- power cone -------------------------------------------------------------------------
-__device__ __forceinline__ ereal pc_x(ereal r, ereal xh, ereal rh, ereal a) { // cones.c:1284-1288
-  const ereal x = (ereal)0.5 * (xh + sqrt(xh * xh + 4 * a * (rh - r) * r));
-  return ec_max(x, (ereal)1e-12);
-}
-__device__ void proj_power_cone_triple(ereal *v, ereal a) { // cones.c:1290-1335
-  const ereal PTOL = (ereal)1e-9;
-  const ereal xh = v[0], yh = v[1], rh = absval(v[2]);
-  ereal x = 0, y = 0, r;
-  if (xh >= 0 && yh >= 0 && PTOL + pow(xh, a) * pow(yh, (1 - a)) >= rh) return;
-  if (xh <= 0 && yh <= 0 && PTOL + pow(-xh, a) * pow(-yh, 1 - a) >= rh * pow(a, a) * pow(1 - a, 1 - a)) {
-    v[0] = v[1] = v[2] = 0;
-    return;
-  }
-  r = rh / 2;
-  for (int i = 0; i < 20; ++i) {
-    x = pc_x(r, xh, rh, a);
-    y = pc_x(r, yh, rh, 1 - a);
-    const ereal xa = pow(x, a), y1a = pow(y, (1 - a));
-    const ereal f = xa * y1a - r;
-    if (absval(f) < PTOL) break;
-    const ereal dxdr = a * (rh - 2 * r) / (2 * x - xh);
-    const ereal dydr = (1 - a) * (rh - 2 * r) / (2 * y - yh);
-    const ereal fp = xa * y1a * (a * dxdr / x + (1 - a) * dydr / y) - 1;
-    r = ec_max(r - f / fp, (ereal)0);
-    r = ec_min(r, rh);
-  }
-  v[0] = x;
-  v[1] = y;
-  v[2] = (v[2] < 0) ? -r : r;
-}
-
-// one lane per cone: [ep primal exp | ed dual exp | psize power (a<0 means dual)]
+// [ep exponential | ed dual exponential | psize power (a < 0: dual power cone)], 3 consecutive rows per cone.
+// A workgroup moves 256 cones per tile through LDS (unit-stride global traffic), one cone per lane.
 __global__ __launch_bounds__(SCSAMD_BLOCK) void k_exp_pow(scs_float *x, int ep, int ed, int psize,
                                                           const scs_float *__restrict__ pw) {
-  const int total = ep + ed + psize;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
-    scs_float *v = x + 3 * (size_t)c;
-    ereal t[3] = {v[0], v[1], v[2]};
-    if (c < ep + ed) {
-      proj_exp_cone_triple(t, c < ep);
-    } else {
-      const ereal a = pw[c - ep - ed];
-      if (a >= 0) {
-        proj_power_cone_triple(t, a);
-      } else { // dual power cone via Moreau, cones.c:1427-1441
-        ereal w[3] = {-t[0], -t[1], -t[2]};
-        proj_power_cone_triple(w, -a);
-        t[0] += w[0];
-        t[1] += w[1];
-        t[2] += w[2];
+  __shared__ scs_float tile[3 * SCSAMD_BLOCK];
+  const int total = ep + ed + psize, tid = threadIdx.x;
+  const int ntiles = (total + SCSAMD_BLOCK - 1) / SCSAMD_BLOCK;
+  for (int tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
+    const int c0 = tb * SCSAMD_BLOCK;
+    const long long v0 = 3LL * c0, vend = 3LL * (c0 + SCSAMD_BLOCK < total ? c0 + SCSAMD_BLOCK : total);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const long long g = v0 + j * SCSAMD_BLOCK + tid;
+      tile[j * SCSAMD_BLOCK + tid] = g < vend ? x[g] : (scs_float)0;
+    }
+    __syncthreads();
+    const int c = c0 + tid;
+    const bool have = c < total;
+    Triple v{tile[3 * tid], tile[3 * tid + 1], tile[3 * tid + 2]};
+    const bool is_exp = have && c < ep + ed, is_pow = have && !is_exp;
+    Triple out = v;
+    if (XP_ANY(is_exp)) {
+      const Triple r = xp::project_exp(v, is_exp, is_exp && c >= ep);
+      if (is_exp) out = r;
+    }
+    if (XP_ANY(is_pow)) {
+      const xreal a_raw = is_pow ? pw[c - ep - ed] : (xreal)0.5;
+      const bool dualp = a_raw < 0; // dual power cone: Moreau, v + Proj_K(-v) (cones.c:1427-1441)
+      const xreal a = dualp ? -a_raw : a_raw;
+      const Triple in{dualp ? -v.u : v.u, dualp ? -v.w : v.w, dualp ? -v.t : v.t};
+      const Triple r = xp::project_pow(in, a, is_pow);
+      if (is_pow) {
+        out.u = dualp ? v.u + r.u : r.u;
+        out.w = dualp ? v.w + r.w : r.w;
+        out.t = dualp ? v.t + r.t : r.t;
       }
     }
-    v[0] = t[0];
-    v[1] = t[1];
-    v[2] = t[2];
+    tile[3 * tid] = out.u;
+    tile[3 * tid + 1] = out.w;
+    tile[3 * tid + 2] = out.t;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const long long g = v0 + j * SCSAMD_BLOCK + tid;
+      if (g < vend) x[g] = tile[j * SCSAMD_BLOCK + tid];
+    }
+    __syncthreads();
   }
 }
 #endif // __HIPCC__
+#endif
 
 } // namespace scsamd

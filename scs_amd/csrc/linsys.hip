@@ -778,8 +778,11 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     use_graph = nnzA <= CG_GRAPH_MAX_NNZ;
     if (const char *e = getenv("SCS_AMD_GRAPH")) use_graph = atoi(e) != 0;
     // two launches per CG iteration (k_cg2_a + the transposed product): n small enough for p in LDS, no P
-    use_cg2 = !use_fused && !has_P && n <= CG2_N_MAX && n >= 2 * RVW;
-    if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && n <= CG2_N_MAX && n >= 2 * RVW;
+    // (k_cg2_a runs the A product through csr_stream_blocks and sums At.grid() partials: not with the wave-owned-rows
+    // layout, whose GP product leaves a different partial count -- very tall A with n <= 1024 takes the four-kernel path)
+    const bool no_wave = !(A.wave && A.wave->built) && !(At.wave && At.wave->built);
+    use_cg2 = !use_fused && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
+    if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
     if (use_cg2) {
       p2.alloc(n);
       r2.alloc(n);
@@ -864,7 +867,7 @@ void LinSys::enqueue_cg2_iteration(long long it) {
   CgCtl *c = ctl.p;
   real *pbuf[2] = {p.p, p2.p}, *rbuf[2] = {r.p, r2.p};
   const int gv = vec_grid(n);
-  const int gAt = At.grid();
+  const int gAt = (At.wave && At.wave->built) ? At.wave->grid() : At.grid(); // partials the GP product really wrote
   real *p_cur = pbuf[it & 1];
   if (it == 0) {
     EpiArgs e1{ry.p, nullptr, nullptr, nullptr};

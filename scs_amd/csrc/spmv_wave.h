@@ -142,9 +142,10 @@ struct WaveRowsDev {
     // nonzero budget per unit: ~8 waves per CU on the whole chip (SCS_AMD_WR_NNZ overrides)
     int dev = 0;
     cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
     long long budget = std::max<long long>(1024, (nnz_all + 8LL * cus - 1) / (8LL * cus));
-    cus = std::max(1, cus);
     if (const char *e = getenv("SCS_AMD_WR_NNZ")) budget = std::max(64, atoi(e));
     std::vector<int> ur, us;
     auto partition = [&](long long bud) {

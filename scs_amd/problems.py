@@ -133,15 +133,34 @@ def random_rows(m, n, col_nnz, rng):
     return r
 
 
-def random_cone_prob(n, m, col_nnz, cone, seed=1234, dtype=np.float64):
+def banded_rows(m, n, col_nnz, band, rng):
+    """n x col_nnz int array: distinct sorted rows per column, uniform over a window of `band` rows centred on the
+    column's own position j m / n (clipped to [0, m)) -- a matrix with the column locality of staged / time-indexed
+    models (MPC, trajectory, multi-period portfolio), where a variable only meets constraints of nearby stages."""
+    band = int(min(max(band, 2 * col_nnz), m))
+    lo = (np.arange(n, dtype=np.int64) * m) // n - band // 2
+    lo = np.clip(lo, 0, m - band)[:, None]
+    r = lo + rng.integers(0, band, size=(n, col_nnz), dtype=np.int64)
+    r.sort(axis=1)
+    while True:
+        dup = np.any(r[:, 1:] == r[:, :-1], axis=1)
+        nd = int(dup.sum())
+        if nd == 0:
+            break
+        r[dup] = np.sort(lo[dup] + rng.integers(0, band, size=(nd, col_nnz), dtype=np.int64), axis=1)
+    return r
+
+
+def random_cone_prob(n, m, col_nnz, cone, seed=1234, dtype=np.float64, band=None):
     """Feasible & bounded random cone program.  Returns dict(A (csc), b, c, cone,
-    x_opt, y_opt, s_opt)."""
+    x_opt, y_opt, s_opt).  `band` (rows): column-local sparsity pattern (banded_rows) instead of the
+    reference generator's uniform one."""
     rng = np.random.default_rng(seed)
     z = rng.uniform(-1, 1, m)
     y = proj_dual_cone_np(z, cone)
     s = y - z
     x = rng.uniform(-1, 1, n)
-    rows = random_rows(m, n, col_nnz, rng)
+    rows = banded_rows(m, n, col_nnz, band, rng) if band else random_rows(m, n, col_nnz, rng)
     vals = rng.uniform(-1, 1, size=(n, col_nnz))
     indptr = np.arange(0, (n + 1) * col_nnz, col_nnz, dtype=np.int64)
     A = sp.csc_matrix((vals.ravel(), rows.ravel(), indptr), shape=(m, n))
@@ -152,12 +171,13 @@ def random_cone_prob(n, m, col_nnz, cone, seed=1234, dtype=np.float64):
     return dict(A=A, b=b.astype(dtype), c=c.astype(dtype), cone=cone, x_opt=x, y_opt=y, s_opt=s)
 
 
-def random_socp(n, m=None, col_nnz=None, seed=1234, q_fixed=None, dtype=np.float64):
-    """The headline family: LP + SOC cones only (BASELINE.json configs 1, 2, 4, 5)."""
+def random_socp(n, m=None, col_nnz=None, seed=1234, q_fixed=None, dtype=np.float64, band=None):
+    """The headline family: LP + SOC cones only (BASELINE.json configs 1, 2, 4, 5).  `band`: the same cones and
+    data law on a column-local (banded) pattern -- the locality variant of bench.py's `secondary`."""
     m = 2 * n if m is None else m
     col_nnz = 10 if col_nnz is None else col_nnz
     cone = socp_cone_sizes(m, q_fixed=q_fixed)
-    return random_cone_prob(n, m, col_nnz, cone, seed=seed, dtype=dtype)
+    return random_cone_prob(n, m, col_nnz, cone, seed=seed, dtype=dtype, band=band)
 
 
 def random_sdp(n, n_blocks=200, block=50, bsize=1001, col_nnz=10, seed=1234):

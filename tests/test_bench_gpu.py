@@ -29,3 +29,33 @@ def test_two_ranks_share_one_gpu_and_report_one_line():
     assert d["results_per_rank"][0][2] != d["results_per_rank"][1][2]  # seed + rank: two different problems
     assert d["batch"]["problems"] == 4 and d["batch"]["all_solved"]
     assert "share_gpu" in d
+
+
+def _run_bench(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                          "--secondary", "batch", "--batch-n", "20000", "--batch-per-gpu", "2", "--batch-concurrency", "2"] + extra,
+                         env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_one_rank_under_torchrun_runs_its_collectives_over_rccl():
+    """the first 8-GPU run must not be the first RCCL run.  `--torchrun` sends the N=1 bench through
+    torch.distributed.run (WORLD_SIZE=1): init_process_group("nccl") (= RCCL on ROCm), the rank census all_gather, the
+    descriptor broadcast, the MAX / SUM all_reduces, the result all_gather, the barriers and the configs[3] batch
+    (broadcast_descriptor + gather_records) all run on cuda tensors.  Same headline problem as the plain N=1 run: the two
+    whole-solve rates agree to 3 %."""
+    plain = _run_bench(["--gpus", "1"])
+    rccl = _run_bench(["--gpus", "1", "--torchrun", "--backend", "nccl"])
+    assert plain["collective_backend"] is None and rccl["collective_backend"] == "nccl"
+    assert rccl["n_gpus"] == 1 and rccl["rccl_ranks_seen"] == [0]
+    assert rccl["status"] == plain["status"] == "solved"
+    assert rccl["iters_to_eps"] == plain["iters_to_eps"]            # bit-reproducible solve, same seed
+    assert rccl["final"]["pobj"] == plain["final"]["pobj"]
+    assert abs(rccl["value"] - plain["value"]) <= 0.03 * plain["value"], (rccl["value"], plain["value"])
+    assert len(rccl["per_rank_it_per_s"]) == 1 and rccl["per_rank_it_per_s"][0] > 0
+    assert rccl["batch"]["problems"] == 2 and rccl["batch"]["all_solved"]

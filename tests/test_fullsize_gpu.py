@@ -46,6 +46,51 @@ def test_linear_solve_kkt_identity_at_full_size(full_problem):
     lib.scs_free_lin_sys_work(w)
 
 
+def test_linear_solve_at_full_size_matches_reference_backend(full_problem):
+    """One scs_solve_lin_sys on the headline problem (n=1e6, m=2e6, nnz=1e7) through the SAME five-function ABI on both
+    sides: libscsamd_linsys.so -- auto-selected wave-owned-rows kernel, default unit budget, resident grid, no environment
+    overrides -- against the reference's linsys/cpu/indirect/private.c:284-324 (oracle/_ref).  diag_r as the ADMM loop
+    builds it (rho_x on x, 1/(1000 scale) on the zero-cone rows, 1/scale elsewhere), warm start, tol 1e-9: both answers
+    solve the same SPD system to 1e-9 in the residual inf-norm, so they agree to 1e-7 of the solution's scale."""
+    import os
+    from oracle import pyoracle
+    from tests import probgen
+    if not pyoracle.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    for v in ("SCS_AMD_WAVEROWS", "SCS_AMD_WR_NNZ", "SCS_AMD_SPMV_MAX_GRID", "SCS_AMD_VEC_MAX_GRID"):
+        assert v not in os.environ
+    pr, prob = full_problem
+    ref = pyoracle.load_ref()
+    amd = capi.load("libscsamd_linsys.so")
+    T = amd._scs_types
+    dr = probgen.diag_r(N, M, z=pr["cone"]["z"])
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, N + M)
+    s = rng.uniform(-1, 1, N) * 0.1
+    outs = []
+    for lib in (amd, ref):
+        w = lib.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
+        assert w
+        o = b.copy()
+        assert lib.scs_solve_lin_sys(w, o.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp), 1e-9) == 0
+        if lib is amd:
+            st = T.ScsAmdStats()
+            amd.scs_amd_linsys_get_stats(w, C.byref(st))
+            assert st.cg_iters > 20 and st.nnz == N * CN
+        lib.scs_free_lin_sys_work(w)
+        outs.append(o)
+    xa, xr = outs
+    scale = np.abs(xr).max()
+    assert np.abs(xa[:N] - xr[:N]).max() <= 1e-7 * scale, np.abs(xa[:N] - xr[:N]).max() / scale
+    assert np.abs(xa[N:] - xr[N:]).max() <= 1e-7 * max(scale, np.abs(xr[N:]).max())
+    # and the reduced KKT residual of OUR answer, independent of either CG path
+    A = prob.sparse()
+    x, y = xa[:N], xa[N:]
+    r2 = A @ x - dr[N:] * y - b[N:]
+    red = dr[:N] * x + A.T @ y - b[:N] + A.T @ (r2 / dr[N:])
+    assert np.abs(red).max() <= 1e-9 * 1.01 + 1e-10 * np.abs(b).max()
+
+
 def test_capped_solve_identities_and_cone_membership_at_full_size(full_problem):
     pr, prob = full_problem
     lib = capi.load("libscsamd.so")

@@ -116,6 +116,8 @@ def test_bench_cpu_baseline_worker_runs_without_a_gpu():
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["threads"] == 1 and d["n"] == 1500 and d["iter"] == 15  # ONE capped run of i0 + k iterations
     assert d["solve_s"] > 0 and d["flavour"] == "libscsindir_ref.so", d
+    # the window [5, 15) is read off the reference's own per-iteration log
+    assert d["window"] == [5, 15] and 0 < d["window_s"] < d["solve_s"] and abs(d["its_per_s"] - 10 / d["window_s"]) < 1e-9
 
 
 def test_bench_gpus_flag_spawns_that_many_ranks():

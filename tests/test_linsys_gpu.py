@@ -138,3 +138,36 @@ def test_wave_rows_spmv_path_equals_reference_and_csr_stream_path(monkeypatch):
         ref.scs_free_lin_sys_work(wr)
         for o in outs:
             assert np.abs(o - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+def test_small_n_very_tall_matrix_with_wave_rows_layout(monkeypatch):
+    """n <= 1024 used to take the two-launch CG path (k_cg2_a) even when the wave-owned-rows layout
+    was built (nnz >= 1e6, or forced), and then summed the wrong number of p'Gp partials.  A very tall A with few
+    columns: forced wave rows + forced two-launch request must give the reference's answer and the CSR-stream path's."""
+    amd = capi.load("libscsamd_linsys.so")
+    from oracle import pyoracle
+    ref = pyoracle.load_ref() if pyoracle.ref_available() else None
+    n, m = 1000, 100000
+    rng = np.random.default_rng(21)
+    A = probgen.random_csc(m, n, 120, seed=8)
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
+    dr = probgen.diag_r(n, m, z=m // 10)
+    b = rng.uniform(-1, 1, n + m)
+    s = rng.uniform(-1, 1, n)
+    outs = {}
+    for wave, cg2 in (("0", "0"), ("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("SCS_AMD_WAVEROWS", wave)
+        monkeypatch.setenv("SCS_AMD_CG2", cg2)
+        monkeypatch.setenv("SCS_AMD_WR_NNZ", "3000")
+        w, out = _solve_with(amd, prob.matA, None, dr, b, s, 1e-12)
+        amd.scs_free_lin_sys_work(w)
+        outs[(wave, cg2)] = out
+    base = outs[("0", "0")]
+    assert np.array_equal(base, outs[("0", "1")])  # two-launch path is bit-identical to the four-kernel path
+    for k, o in outs.items():
+        assert np.abs(o - base).max() <= 1e-9 * np.abs(base).max(), k
+    if ref is not None:
+        wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
+        ref.scs_free_lin_sys_work(wr)
+        for k, o in outs.items():
+            assert np.abs(o - xr).max() <= 1e-8 * np.abs(xr).max(), k

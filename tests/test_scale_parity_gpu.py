@@ -39,10 +39,10 @@ def _rel(a, b, floor=1e-3):
 
 def test_wave_rows_kernel_inside_a_solve_matches_reference_exact_cg(monkeypatch):
     ref = _ref("libscsindir_ref_exactcg.so")
-    monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")   # below ~headline size the library would pick csr_stream
+    monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")   # below 1e6 nonzeros the library would pick csr_stream
     monkeypatch.setenv("SCS_AMD_WR_NNZ", "1500")  # ~270 units per orientation: several units per wave too
     amd = capi.load("libscsamd.so")
-    n, m, iters = 40000, 80000, 12
+    n, m, iters = 40000, 80000, 12  # (n = 4e4: the exact-CG reference needs ~1 s per ADMM iteration here)
     pr = problems.random_socp(n, m, 10, seed=77)
     prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
     kw = dict(verbose=0, acceleration_lookback=0, max_iters=iters)
@@ -117,6 +117,58 @@ def test_fp32_at_1e5_against_fp32_reference_and_known_optimum(monkeypatch):
     assert res_pri <= 2 * (eps + eps * max(np.abs(b).max(), np.abs(sv).max(), np.abs(A @ x).max()))
     assert res_dual <= 2 * (eps + eps * max(np.abs(c).max(), np.abs(A.T @ y).max()))
     assert abs(c @ x + b @ y) <= 2 * (eps + eps * max(abs(c @ x), abs(b @ y)))
+
+
+def test_fp32_at_5e5_linear_solve_and_capped_window_against_fp32_reference():
+    """fp32 at n = 5e5 (m = 1e6, nnz = 5e6: the wave-owned-rows kernel selects itself), against the reference's SFLOAT
+    build through the same ABI.
+    (i) one scs_solve_lin_sys, tol 1e-4, warm start: both fp32 answers are compared with the fp64 solution of the same
+        system (libscsamd_linsys.so at tol 1e-12): ours must be as close to it as the reference's is (within 2x), and both
+        within what tol 1e-4 on a system with lambda_min ~ 1e-2 allows;
+    (ii) a window of ADMM iterations, capped identically on both sides (the fp32 reference needs seconds per iteration
+        here): same iteration count, objectives within 5e-2 of their scale, residuals within 2x -- inexact fp32 CG with
+        different summation orders, DESIGN.md section 4 (the fp64 builds get 1e-6 with exact CG; CG_BEST_TOL = 1e-12 is out of
+        reach of fp32 arithmetic, so there is no exact-CG fp32 reference to compare trajectories with)."""
+    import ctypes as C
+    from tests import probgen
+    ref = _ref("libscsindir_ref_f32.so")
+    amd = capi.load("libscsamd_f32.so")
+    amd64 = capi.load("libscsamd_linsys.so")
+    n, m = 500000, 1000000
+    pr = problems.random_socp(n, m, 10, seed=11, dtype=np.float32)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=capi.T32)
+    prob64 = capi.Problem(pr["A"].astype(np.float64), np.zeros(m), np.zeros(n), dict(l=m))
+    # (i)
+    dr = probgen.diag_r(n, m, z=pr["cone"]["z"])
+    rng = np.random.default_rng(2)
+    b = rng.uniform(-1, 1, n + m)
+    s = rng.uniform(-1, 1, n) * 0.1
+    sols = {}
+    for name, lib, P, f in (("amd", amd, prob, np.float32), ("ref", ref, prob, np.float32), ("f64", amd64, prob64, np.float64)):
+        T = lib._scs_types
+        d = dr.astype(f)
+        w = lib.scs_init_lin_sys_work(C.byref(P.matA), None, d.ctypes.data_as(T.fp))
+        assert w
+        o, sw = b.astype(f), s.astype(f)
+        assert lib.scs_solve_lin_sys(w, o.ctypes.data_as(T.fp), sw.ctypes.data_as(T.fp), 1e-12 if name == "f64" else 1e-4) == 0
+        lib.scs_free_lin_sys_work(w)
+        sols[name] = o.astype(np.float64)
+    scale = np.abs(sols["f64"][:n]).max()
+    ea = np.abs(sols["amd"][:n] - sols["f64"][:n]).max() / scale
+    er = np.abs(sols["ref"][:n] - sols["f64"][:n]).max() / scale
+    assert ea <= 2e-2 and er <= 2e-2, (ea, er)       # tol / lambda_min, with lambda_min of R_x + A' R_y^-1 A ~ 1e-2
+    assert ea <= 2.0 * er + 1e-4, (ea, er)           # as accurate as the reference's own fp32 solve
+    # (ii)
+    iters = 8
+    kw = dict(verbose=0, acceleration_lookback=0, eps_abs=1e-3, eps_rel=1e-3, max_iters=iters)
+    ra, rr = capi.solve(amd, prob, **kw), capi.solve(ref, prob, **kw)
+    ia, ir = ra["info"], rr["info"]
+    assert ia["iter"] == ir["iter"] == iters
+    sc = max(1.0, abs(ir["pobj"]), abs(ir["dobj"]))
+    assert abs(ia["pobj"] - ir["pobj"]) <= 5e-2 * sc, (ia["pobj"], ir["pobj"])
+    assert abs(ia["dobj"] - ir["dobj"]) <= 5e-2 * sc, (ia["dobj"], ir["dobj"])
+    for k in ("res_pri", "res_dual"):
+        assert 0.5 <= ia[k] / ir[k] <= 2.0, (k, ia[k], ir[k])
 
 
 def test_reference_random_socp_prob_program_over_our_library():
