@@ -22,17 +22,6 @@ struct CgCtl {
   int cg_done;   // converged (or breakdown): remaining iteration kernels return
   int iters;     // PCG iterations performed (reference counting, private.c:203,216)
   int max_its;   // 10 n (private.c:307): the device stops there even if more iterations were enqueued
-  unsigned epoch; // grid barriers completed so far by the fused update+direction kernel (monotonic, never reset)
-  unsigned fault; // a bounded spin of that barrier ran out: the solve is reported as failed
-};
-
-// arrival words of the fused kernel's grid barrier: eight group counters (blockIdx % 8 -- the dispatcher places
-// consecutive workgroups on consecutive XCDs; used for speed only), a top counter, the generation everybody polls;
-// 128 bytes apart; monotonic, so nothing is re-initialised between launches
-struct GridBarrierWords {
-  unsigned grp[8 * 32];
-  unsigned top[32];
-  unsigned gen[32];
 };
 
 struct LinSys {
@@ -42,9 +31,6 @@ struct LinSys {
   bool has_P = false;
   bool use_fused = false; // whole solve in one workgroup (small systems)
   bool use_cg2 = false;   // two launches per CG iteration (n <= CG2_N_MAX): k_cg2_a + transposed product
-  bool use_updir = false; // three launches per CG iteration: update + direction fused behind one grid barrier (k_cg_updir)
-  bool updir_now = false; // ... and in force for the current solve (few enough workspaces alive)
-  DevBuf<GridBarrierWords> gbar;
 
   CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector
   CsrDev A;  // CSR(A): m rows, gathers an n-vector
@@ -77,7 +63,7 @@ struct LinSys {
   EventTimer spmv_timer, cg_timer;
   long long spmv_sample_ctr = 0;
 
-  LinSys();
+  LinSys() = default;
   ~LinSys();
   LinSys(const LinSys &) = delete;
 

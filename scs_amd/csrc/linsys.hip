@@ -284,142 +284,6 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const re
   }
 }
 
-// ----------------------------------------------------------------------------
-// k_cg_update + k_cg_direction in ONE launch (private.c:181-214): the workgroups meet at a grid barrier between the two
-// halves, every lane keeps its chunks of p and z in registers across it -- z is never written, p and z are not read
-// again (24 of the 88 MB the two kernels move at n = 1e6) and one kernel boundary disappears.  Same lane -> chunk
-// mapping, same accumulation order, same partial arrays and the same fixed-order re-reduction as the two kernels:
-// bit-identical iterates.  The grid (vec_grid(n) <= 512 workgroups of 256 lanes = 2 per CU) must be co-resident: the
-// host only takes this path while at most two solver workspaces are alive in the process, every spin is bounded and a
-// spin that runs out raises ctl->fault, which the host turns into a failed solve.
-// ----------------------------------------------------------------------------
-constexpr int UPDIR_MAX_CHUNKS = 8; // vector chunks (16 B) a lane may hold across the barrier: n <= 8 * 512 * 256 * RVW
-
-__device__ __forceinline__ bool cg_grid_barrier(GridBarrierWords *bar, unsigned E, CgCtl *ctl) {
-  __shared__ int passed;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned g = blockIdx.x & 7u, members = (gridDim.x - g + 7u) / 8u, ngrp = gridDim.x < 8u ? gridDim.x : 8u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-back has landed before the arrival is counted
-    const unsigned a = __hip_atomic_fetch_add(&bar->grp[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a + 1u == E * members) {
-      const unsigned t = __hip_atomic_fetch_add(&bar->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1u == E * ngrp) __hip_atomic_store(&bar->gen[0], E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    int ok = 0;
-    for (unsigned spin = 0; spin < (1u << 22); ++spin) { // ~ seconds; a healthy barrier takes microseconds
-      if (__hip_atomic_load(&bar->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= E) {
-        ok = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (!ok) __hip_atomic_store(&ctl->fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    passed = ok;
-  }
-  __syncthreads();
-  return passed != 0;
-}
-
-template <int CH>
-__global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_updir(real *x, real *r, real *p, const real *__restrict__ Gp,
-                                                           const real *__restrict__ M, int n, const real *part_pgp,
-                                                           int cnt_pgp, real *part_ztr, real *part_max, CgCtl *ctl,
-                                                           GridBarrierWords *bar, int parity) {
-  __shared__ real red[4];
-  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
-  const int nv = n / RVW;
-  const int done = ctl->cg_done;
-  const unsigned E = ctl->epoch + 1u;
-  const real ztr_in = ctl->ztr[parity], tol = ctl->tol;
-  real psum = 0;
-  for (int i = threadIdx.x; i < cnt_pgp; i += blockDim.x) psum += part_pgp[i];
-  if (done) return; // uniform over the grid: cg_done only changes at the end of a launch
-  const real pgp = block_sum(psum, red);
-  const real alpha = ztr_in / pgp;
-  real ztr = 0, mx = 0;
-  rvec Pk[CH], Zk[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int iv = gtid + c * gs;
-    if (iv < nv) {
-      const rvec P = ldv(p, iv), G = ldv(Gp, iv), Mv = ldv(M, iv);
-      rvec X = ldv(x, iv), R = ldv(r, iv), Z;
-#pragma unroll
-      for (int e = 0; e < RVW; ++e) {
-        X.v[e] += alpha * P.v[e];
-        const real ri = R.v[e] + (-alpha) * G.v[e];
-        R.v[e] = ri;
-        const real zi = ri * Mv.v[e];
-        Z.v[e] = zi;
-        ztr += zi * ri;
-        const real a = absval(ri);
-        mx = a > mx ? a : mx;
-      }
-      stv(x, iv, X);
-      stv(r, iv, R);
-      Pk[c] = P;
-      Zk[c] = Z;
-    }
-  }
-  // scalar tail (n not a multiple of the vector width): p and z of at most RVW - 1 entries, owned by the first lanes
-  real pt = 0, zt = 0;
-  const int it = nv * RVW + gtid;
-  if (it < n) {
-    const real pi = p[it], gi = Gp[it];
-    x[it] += alpha * pi;
-    const real ri = r[it] + (-alpha) * gi;
-    r[it] = ri;
-    const real zi = ri * M[it];
-    ztr += zi * ri;
-    const real a = absval(ri);
-    mx = a > mx ? a : mx;
-    pt = pi;
-    zt = zi;
-  }
-  ztr = block_sum(ztr, red);
-  mx = block_max(mx, red);
-  if (threadIdx.x == 0) {
-    part_ztr[blockIdx.x] = ztr;
-    part_max[blockIdx.x] = mx;
-  }
-  if (!cg_grid_barrier(bar, E, ctl)) return;
-  // ---- direction: same re-reduction of the partials as k_cg_direction
-  real zs = 0, ms = 0;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
-    zs += part_ztr[i];
-    const real v = part_max[i];
-    ms = v > ms ? v : ms;
-  }
-  const real ztr_new = block_sum(zs, red);
-  const real nr = block_max(ms, red);
-  const bool conv = nr < tol;
-  const bool brk = !conv && ztr_in == (real)0;
-  if (!conv && !brk) {
-    const real beta = ztr_new / ztr_in;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int iv = gtid + c * gs;
-      if (iv < nv) {
-        rvec P = Pk[c];
-#pragma unroll
-        for (int e = 0; e < RVW; ++e) P.v[e] = Zk[c].v[e] + beta * P.v[e];
-        stv(p, iv, P);
-      }
-    }
-    if (it < n) p[it] = zt + beta * pt;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ctl->ztr[parity ^ 1] = ztr_new;
-    ctl->norm_r = nr;
-    ctl->epoch = E;
-    if (!brk) ctl->iters += 1;
-    if (conv || brk || ctl->iters >= ctl->max_its) ctl->cg_done = 1;
-  }
-}
-
 // private.c:50-82, one lane per column of A (= row of CSR(A'))
 __global__ __launch_bounds__(SCSAMD_BLOCK) void k_precond(CsrView At, const real *__restrict__ rx,
                                                           const real *__restrict__ ry,
@@ -757,12 +621,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_linsys_fused(CsrView A, CsrVi
 // ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
-static std::atomic<int> g_live_linsys{0}; // solver workspaces alive in this process (co-residency guard of k_cg_updir)
-
-LinSys::LinSys() { g_live_linsys.fetch_add(1, std::memory_order_relaxed); }
-
 LinSys::~LinSys() {
-  g_live_linsys.fetch_sub(1, std::memory_order_relaxed);
   if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
   if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -925,15 +784,6 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     const bool no_wave = !(A.wave && A.wave->built) && !(At.wave && At.wave->built);
     use_cg2 = !use_fused && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
     if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
-    // update + direction in one launch behind a grid barrier (k_cg_updir): SCS_AMD_CGFUSE=1 asks for it
-    {
-      const long long lanes = (long long)vec_grid(n) * SCSAMD_BLOCK;
-      const bool fits = ((long long)n / RVW + lanes - 1) / lanes <= UPDIR_MAX_CHUNKS;
-      use_updir = false;
-      if (const char *e = getenv("SCS_AMD_CGFUSE")) use_updir = atoi(e) != 0;
-      use_updir = use_updir && fits && !use_fused && !use_cg2;
-      if (use_updir) gbar.alloc(1);
-    }
     if (use_cg2) {
       p2.alloc(n);
       r2.alloc(n);
@@ -1010,7 +860,9 @@ void LinSys::harvest_timers() {
 
 
 // one PCG iteration = K1 (z = R_y^-1 A p), [P p], K2 (Gp, partial p'Gp), K3 (alpha, x, r, z, partial
-// z'r, |r|), K4 (stop test, beta, p); `b` is where the solve keeps x: always b_stage / the caller's
+// z'r, |r|), K4 (stop test, beta, p).  K3 and K4 stay two launches: fused behind a grid barrier (p and z in registers
+// across it, z never written) they were bit-identical and SLOWER -- 184 vs 172 us per CG iteration at n = 1e6, 48 vs 39
+// at n = 2e5 in the solver, vector part 33.7 vs 21.8 us in lab/cgfuse_lab.hip (profiles/r3_cgfuse_lab.md); `b` is where the solve keeps x: always b_stage / the caller's
 // device vector, fixed per LinSys user, so it is passed through cg_x
 // small systems: iteration `it` >= 1 = k_cg2_a (update + direction of iteration it-1, then z = R_y^-1 A p_it) and the
 // transposed product; p_j lives in pbuf[j & 1].  Iteration 0 (no update yet) uses the plain A product.
@@ -1046,18 +898,6 @@ void LinSys::enqueue_cg_iteration(int q) {
   }
   EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, part_pgp};
   launch_spmv(EPI_GP, At, tmp.p, Gp.p, e2, &c->cg_done);
-  if (updir_now) { // update + direction behind one grid barrier; p and z ride in registers across it
-    const int chunks = (int)(((long long)n / RVW + (long long)gv * SCSAMD_BLOCK - 1) / ((long long)gv * SCSAMD_BLOCK));
-#define LAUNCH_UPDIR(CH)                                                                                                \
-  hipLaunchKernelGGL(k_cg_updir<CH>, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, cg_x, r.p, p.p, Gp.p, M.p, n, part_pgp, gAt,  \
-                     part_ztr, part_max, c, gbar.p, q)
-    if (chunks <= 1) LAUNCH_UPDIR(1);
-    else if (chunks <= 2) LAUNCH_UPDIR(2);
-    else if (chunks <= 4) LAUNCH_UPDIR(4);
-    else LAUNCH_UPDIR(8);
-#undef LAUNCH_UPDIR
-    return;
-  }
   hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, cg_x, r.p, z.p, p.p, Gp.p, M.p, n,
                      part_pgp, gAt, part_ztr, part_max, c, q);
   hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, part_ztr, part_max,
@@ -1099,14 +939,11 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
   const int gv = vec_grid(n), gnm = vec_grid((long long)n + m);
   CgCtl *c = ctl.p;
   static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
-  // the fused update+direction kernel needs its whole grid resident: only while few workspaces share the device
-  const bool updir_next = use_updir && g_live_linsys.load(std::memory_order_relaxed) <= 2;
-  if (cg_x != b || updir_next != updir_now) { // the captured graph bakes the solution vector's address and the variant in
+  if (cg_x != b) { // the captured graph bakes the solution vector's address in
     if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
     cg_graph = nullptr;
     cg_graph_tried = false;
     cg_x = b;
-    updir_now = updir_next;
   }
   int cg_slot = -1;
   if (profiling) cg_slot = cg_timer.start(stream);
@@ -1189,7 +1026,6 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
       fprintf(stderr, "[scs_amd pcg] enq=%lld iters=%d done=%d zero=%d |r|=%.3e tol=%.3e ztr=(%.3e,%.3e) |b|=%.3e\n",
               it, hctl.p->iters, hctl.p->cg_done, hctl.p->zero_rhs, (double)hctl.p->norm_r,
               (double)hctl.p->tol, (double)hctl.p->ztr[0], (double)hctl.p->ztr[1], (double)hctl.p->rhs_norm);
-    if (hctl.p->fault) throw HipError("scs_amd: grid barrier of the fused PCG kernel timed out (workgroups not co-resident)");
     if (hctl.p->cg_done || it >= max_its + (use_cg2 ? 1 : 0)) break;
     batch = std::max(4, std::min(last_its / 4 + 1, 1024));
   }

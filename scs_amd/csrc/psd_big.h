@@ -43,8 +43,12 @@ struct BigPsdView {
   BigPsdCtl *ctl;         // nbig
 };
 
+constexpr int BJ_B = 32;       // blocked iteration: width of a block column
+constexpr int BJ_W = 2 * BJ_B; // order of the subproblem of a pair of block columns
+
 struct BlockShape {
   int k, K2, nn, npairs;
+  int K64, nbc; // blocked iteration: order padded to whole pairs of block columns, number of block columns (even)
   bool cplx;
 };
 __device__ __forceinline__ BlockShape bp_shape_raw(int kraw) {
@@ -54,19 +58,22 @@ __device__ __forceinline__ BlockShape bp_shape_raw(int kraw) {
   s.nn = s.k / 2;
   s.K2 = (s.k + 1) & ~1;
   s.npairs = s.K2 / 2;
+  s.K64 = (s.k + BJ_W - 1) / BJ_W * BJ_W;
+  s.nbc = s.K64 / BJ_B;
   return s;
 }
 __device__ __forceinline__ BlockShape bp_shape(const BigPsdView &B, int b) { return bp_shape_raw(B.psd_k[B.id[b]]); }
 
 // A <- unpacked block (diagonal * sqrt 2), V <- I
-__global__ __launch_bounds__(BP_THREADS) void k_bp_unpack(BigPsdView B, const real *__restrict__ x, int set_identity) {
+__global__ __launch_bounds__(BP_THREADS) void k_bp_unpack(BigPsdView B, const real *__restrict__ x, int set_identity, int blocked) {
   const int b = blockIdx.y;
   const BlockShape s = bp_shape(B, b);
   const real *X = x + B.psd_off[B.id[b]];
   real *A = B.A + (size_t)b * B.ld * B.ld, *V = B.V + (size_t)b * B.ld * B.ld;
-  const long long total = (long long)s.K2 * s.K2;
+  const int span = blocked ? s.K64 : s.K2; // the blocked iteration works on whole pairs of block columns: zero rows / columns, unit diagonal in V
+  const long long total = (long long)span * span;
   for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * BP_THREADS) {
-    const int i = (int)(e % s.K2), j = (int)(e / s.K2);
+    const int i = (int)(e % span), j = (int)(e / span);
     A[(size_t)j * B.ld + i] = psd_unpack_entry(X, s.k, s.cplx, s.nn, i, j);
     if (set_identity) V[(size_t)j * B.ld + i] = i == j ? (real)1 : (real)0;
   }
@@ -227,6 +234,250 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_step(BigPsdView B, int arg) {
       V[ip] = r2.c * vp - r2.s * vq;
       V[iq] = r2.s * vp + r2.c * vq;
     }
+  }
+}
+
+// =====================================================================================================================
+// Blocked iteration: the round-robin tournament runs over BLOCK COLUMNS of width 32 instead of single
+// columns.  One outer step pairs the block columns (I, J); for every pair
+//   k_bj_inner   one workgroup pulls the 64 x 64 subproblem S = A[IJ, IJ] into LDS, runs ONE sweep of the same parallel
+//                cyclic Jacobi rotations as k_psd_jacobi on it (63 inner steps, same formulas, same threshold, exact zero
+//                for a rotated pair's own entry) and leaves the accumulated orthogonal factor Q (64 x 64), the rotated
+//                subproblem S' = Q' S Q and a "rotated at all" flag in HBM;
+//   k_bj_update  applies the step to the whole matrix on the fp64 matrix cores: tile (P, Q) of the double-buffered A
+//                becomes Q_P' A[P, Q] Q_Q (two 64^3 products per workgroup, operands staged in LDS with a leading
+//                dimension of 66 so that the v_mfma_f64_16x16x4 operand reads are bank-conflict free), the diagonal tiles
+//                take S' as the inner sweep left it (rotation arithmetic keeps its tiny entries relatively accurate and
+//                its zeros exact; a GEMM would refill them with rounding noise of the diagonal's size), and the
+//                eigenvector tiles V[:, Q] <- V[:, Q] Q_Q.
+// A sweep is nbc - 1 outer steps of two launches each instead of K - 1 launches (1024 x 1024: 62 launches instead of 1023)
+// and the O(K^3) work of a sweep moves onto the matrix cores.  Convergence (largest off-diagonal entry met during a sweep
+// <= eps |A|_F / k), sweep cap, warm start and reconstruction are unchanged.  Padding rows / columns (order rounded up to a
+// multiple of 64) are zero in A and unit in V; a rotation never touches them (q < k, as in the LDS kernel).
+constexpr int BJ_LD = BJ_W + 2;        // LDS leading dimension of the product operands (66: rows 2 banks apart)
+constexpr int BJ_ILD = BJ_W | 1;       // LDS leading dimension of the rotation sweep (65: row and column walks conflict free)
+constexpr int BJ_INNER_THREADS = 512;
+constexpr size_t BJ_INNER_LDS = (size_t)2 * BJ_W * BJ_ILD * sizeof(real) + BJ_B * (sizeof(RotCS) + sizeof(int2));
+constexpr size_t BJ_UPDATE_LDS = (size_t)4 * BJ_W * BJ_LD * sizeof(real);
+
+__device__ __forceinline__ int2 bj_pair(int i, int step, int nbc) { // round robin over block columns, as over columns
+  int I = i == 0 ? 0 : 1 + ((i - 1 + step) % (nbc - 1));
+  int J = 1 + ((nbc - 2 - i + step) % (nbc - 1));
+  if (I > J) {
+    const int t = I;
+    I = J;
+    J = t;
+  }
+  return make_int2(I, J);
+}
+// global row / column of local index l (0..63) of the pair (I, J)
+__device__ __forceinline__ int bj_gidx(int2 IJ, int l) { return l < BJ_B ? IJ.x * BJ_B + l : IJ.y * BJ_B + (l - BJ_B); }
+
+// Qbuf / Sbuf: per (block, pair) 64 x 64 column-major; Qflag: 1 if the sweep rotated anything
+__global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, real *Qbuf, real *Sbuf, int *Qflag, int npmax, int arg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
+  real *S = reinterpret_cast<real *>(bj_smem);
+  real *Q = S + BJ_W * BJ_ILD;
+  RotCS *rot_cs = reinterpret_cast<RotCS *>(Q + BJ_W * BJ_ILD);
+  int2 *rot_pq = reinterpret_cast<int2 *>(rot_cs + BJ_B);
+  __shared__ real red[BJ_INNER_THREADS / SCSAMD_WAVE];
+  __shared__ volatile int rot_any[2];
+  __shared__ int rotated;
+  const int slot = arg & 1, step = arg >> 1;
+  const int b = blockIdx.y, pi = blockIdx.x, tid = threadIdx.x;
+  BigPsdCtl *ctl = B.ctl + b;
+  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
+  const real thr = ctl->thr;
+  const BlockShape sh = bp_shape_raw(kraw);
+  if (done || step >= sh.nbc - 1 || pi >= sh.nbc / 2) return;
+  const int2 IJ = bj_pair(pi, step, sh.nbc);
+  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
+  const real *Aold = (cur ? B.A1 : B.A) + mat;
+  const int k = sh.k;
+  for (int e = tid; e < BJ_W * BJ_W; e += BJ_INNER_THREADS) {
+    const int r = e & (BJ_W - 1), c = e >> 6; // r fast: 32-entry runs of a column of A
+    S[r * BJ_ILD + c] = Aold[(size_t)bj_gidx(IJ, c) * ld + bj_gidx(IJ, r)];
+    Q[r * BJ_ILD + c] = r == c ? (real)1 : (real)0;
+  }
+  if (tid < 2) rot_any[tid] = 0;
+  if (tid == 0) rotated = 0;
+  __syncthreads();
+  real offmax = 0;
+  constexpr int NP = BJ_B; // 32 pairs of the 64 local indices
+  for (int st = 0; st < BJ_W - 1; ++st) {
+    const int par = st & 1;
+    if (tid < NP) {
+      const int i = tid;
+      int p = i == 0 ? 0 : 1 + ((i - 1 + st) % (BJ_W - 1));
+      int q = 1 + ((BJ_W - 2 - i + st) % (BJ_W - 1));
+      if (p > q) {
+        const int t = p;
+        p = q;
+        q = t;
+      }
+      real c = 1, s = 0;
+      const real apq = S[p * BJ_ILD + q];
+      const real aa = absval(apq);
+      const bool real_pair = bj_gidx(IJ, q) < k; // local order = global order (I < J): q is the larger index
+      if (real_pair) offmax = aa > offmax ? aa : offmax;
+      if (real_pair && aa > thr) {
+        const real d = S[q * BJ_ILD + q] - S[p * BJ_ILD + p], bb = (real)2 * apq;
+        const real h = sqrt(d * d + bb * bb);
+        const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
+        c = rsqrt(t * t + (real)1);
+        s = t * c;
+        rot_any[par] = 1;
+      }
+      rot_pq[i] = make_int2(p, q);
+      rot_cs[i] = RotCS{c, s};
+      if (i == 0) rot_any[par ^ 1] = 0;
+    }
+    __syncthreads();
+    if (!rot_any[par]) continue; // uniform
+    if (tid == 0) rotated = 1;
+    for (int e = tid; e < NP * NP + BJ_W * NP; e += BJ_INNER_THREADS) {
+      if (e < NP * NP) {
+        const int Qi = e / NP, P = e % NP;
+        const int2 pq1 = rot_pq[P], pq2 = rot_pq[Qi];
+        const RotCS r1 = rot_cs[P], r2 = rot_cs[Qi];
+        const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
+        const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
+        const int i11 = p1 * BJ_ILD + p2, i12 = p1 * BJ_ILD + q2, i21 = q1 * BJ_ILD + p2, i22 = q1 * BJ_ILD + q2;
+        const real a11 = S[i11], a12 = S[i12], a21 = S[i21], a22 = S[i22];
+        const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
+        const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
+        const bool own = P == Qi && s1 != (real)0;
+        S[i11] = c2 * r11 - s2 * r12;
+        S[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
+        S[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
+        S[i22] = s2 * r21 + c2 * r22;
+      } else {
+        const int f = e - NP * NP, Qi = f / BJ_W, i = f % BJ_W;
+        const int2 pq2 = rot_pq[Qi];
+        const RotCS r2 = rot_cs[Qi];
+        const int ip = i * BJ_ILD + pq2.x, iq = i * BJ_ILD + pq2.y;
+        const real vp = Q[ip], vq = Q[iq];
+        Q[ip] = r2.c * vp - r2.s * vq;
+        Q[iq] = r2.s * vp + r2.c * vq;
+      }
+    }
+    __syncthreads();
+  }
+  offmax = block_max(offmax, red); // (contains the barriers that make `rotated` and the last pass visible)
+  if (tid == 0) {
+    if (offmax > (real)0) atomicMax(&ctl->offmax_bits, bp_bits(offmax));
+    Qflag[(size_t)b * npmax + pi] = rotated;
+  }
+  if (!rotated) return; // uniform: nobody reads Q / S' of a pair whose flag is 0
+  real *Qg = Qbuf + ((size_t)b * npmax + pi) * BJ_W * BJ_W, *Sg = Sbuf + ((size_t)b * npmax + pi) * BJ_W * BJ_W;
+  for (int e = tid; e < BJ_W * BJ_W; e += BJ_INNER_THREADS) {
+    const int r = e & (BJ_W - 1), c = e >> 6;
+    Qg[c * BJ_W + r] = Q[r * BJ_ILD + c];
+    Sg[c * BJ_W + r] = S[r * BJ_ILD + c];
+  }
+}
+
+// O[i][j] = sum_k L[i][k] R[k][j] for 64 x 64 operands in LDS: L[i][k] at L[i * BJ_LD + k], R[k][j] at R[j * BJ_LD + k] (both
+// contiguous along the summation index), O[i][j] at O[j * BJ_LD + i].  Four waves, four 16 x 16 tiles each; lane
+// (li = l & 15, lk = l >> 4) supplies L[16 ti + li][4 ks + lk] and R[4 ks + lk][16 tj + li].
+__device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O, int tid) {
+#ifndef SFLOAT
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  for (int t = wave; t < 16; t += BP_THREADS / SCSAMD_WAVE) {
+    const int ti = t & 3, tj = t >> 2;
+    const real *lp = L + (ti * 16 + li) * BJ_LD + lk, *rp = R + (tj * 16 + li) * BJ_LD + lk;
+    f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < BJ_W / 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lp[ks * 4], rp[ks * 4], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) O[(tj * 16 + li) * BJ_LD + ti * 16 + lk + 4 * r] = acc[r];
+  }
+#else
+  for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+    const int i = e & (BJ_W - 1), j = e >> 6;
+    real acc = 0;
+    for (int kk = 0; kk < BJ_W; ++kk) acc += L[i * BJ_LD + kk] * R[j * BJ_LD + kk];
+    O[j * BJ_LD + i] = acc;
+  }
+#endif
+}
+
+__global__ __launch_bounds__(BP_THREADS) void k_bj_update(BigPsdView B, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
+                                                          const int *__restrict__ Qflag, int npmax, int arg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
+  real *xs = reinterpret_cast<real *>(bj_smem);
+  real *qp = xs + BJ_W * BJ_LD, *qq = qp + BJ_W * BJ_LD, *ts = qq + BJ_W * BJ_LD;
+  const int slot = arg & 1, step = arg >> 1;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  BigPsdCtl *ctl = B.ctl + b;
+  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
+  const BlockShape sh = bp_shape_raw(kraw);
+  const bool active = !done && step < sh.nbc - 1;
+  if (blockIdx.x == 0 && tid == 0) ctl->cur[slot ^ 1] = active ? cur ^ 1 : cur;
+  if (!active) return;
+  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
+  const real *Aold = (cur ? B.A1 : B.A) + mat;
+  real *Anew = (cur ? B.A : B.A1) + mat;
+  real *V = B.V + mat;
+  const int np = sh.nbc / 2, nta = np * np, TR = sh.K64 / BJ_W;
+  int tile = blockIdx.x;
+  if (tile >= nta + np * TR) return;
+  const int *flags = Qflag + (size_t)b * npmax;
+  const real *Qb = Qbuf + (size_t)b * npmax * BJ_W * BJ_W, *Sb = Sbuf + (size_t)b * npmax * BJ_W * BJ_W;
+  if (tile < nta) {
+    const int Pp = tile % np, Qp = tile / np;
+    const int2 IJp = bj_pair(Pp, step, sh.nbc), IJq = bj_pair(Qp, step, sh.nbc);
+    const int fP = flags[Pp], fQ = flags[Qp];
+    if (Pp == Qp && fP) { // the pair's own tile: the inner sweep's S' (exact zeros, relatively accurate small entries)
+      for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+        const int i = e & (BJ_W - 1), j = e >> 6;
+        Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = Sb[(size_t)Pp * BJ_W * BJ_W + j * BJ_W + i];
+      }
+      return;
+    }
+    if (!fP && !fQ) { // neither pair rotated: the tile moves to the other copy as it is
+      for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+        const int i = e & (BJ_W - 1), j = e >> 6;
+        const size_t g = (size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i);
+        Anew[g] = Aold[g];
+      }
+      return;
+    }
+    // X[i][k] = A[P_i, Q_k]; Q_Q[k][j] and Q_P[k][i], identity where the pair did not rotate
+    for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+      const int i = e & (BJ_W - 1), kk = e >> 6;
+      xs[i * BJ_LD + kk] = Aold[(size_t)bj_gidx(IJq, kk) * ld + bj_gidx(IJp, i)];
+      // Qbuf is column-major: Q[k][j] at j * 64 + k -> qq[j * BJ_LD + k]: here (kk, i) play (j, k)
+      qq[kk * BJ_LD + i] = fQ ? Qb[(size_t)Qp * BJ_W * BJ_W + kk * BJ_W + i] : (i == kk ? (real)1 : (real)0);
+      qp[kk * BJ_LD + i] = fP ? Qb[(size_t)Pp * BJ_W * BJ_W + kk * BJ_W + i] : (i == kk ? (real)1 : (real)0);
+    }
+    __syncthreads();
+    bj_gemm64(xs, qq, ts, tid); // T = X Q_Q, T[i][j] at ts[j * BJ_LD + i]
+    __syncthreads();
+    bj_gemm64(qp, ts, xs, tid); // O = Q_P' T: L[i][k] = Q_P[k][i] = qp[i * BJ_LD + k], R[k][j] = T[k][j] = ts[j * BJ_LD + k]
+    __syncthreads();
+    for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+      const int i = e & (BJ_W - 1), j = e >> 6;
+      Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = xs[j * BJ_LD + i];
+    }
+    return;
+  }
+  // ---- V[:, Q] <- V[:, Q] Q_Q on a tile of 64 rows (in place: the workgroup owns the entries it rewrites)
+  tile -= nta;
+  const int Qp = tile / TR, r0 = (tile % TR) * BJ_W;
+  if (!flags[Qp]) return;
+  const int2 IJq = bj_pair(Qp, step, sh.nbc);
+  for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+    const int i = e & (BJ_W - 1), kk = e >> 6;
+    xs[i * BJ_LD + kk] = V[(size_t)bj_gidx(IJq, kk) * ld + r0 + i];
+    qq[kk * BJ_LD + i] = Qb[(size_t)Qp * BJ_W * BJ_W + kk * BJ_W + i];
+  }
+  __syncthreads();
+  bj_gemm64(xs, qq, ts, tid);
+  __syncthreads();
+  for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+    const int i = e & (BJ_W - 1), j = e >> 6;
+    V[(size_t)bj_gidx(IJq, j) * ld + r0 + i] = ts[j * BJ_LD + i];
   }
 }
 
@@ -425,6 +676,9 @@ struct BigPsd {
   DevBuf<int> remaining;
   long long sweeps_total = 0, projections = 0;
   bool warm_ok = true;
+  bool blocked = true;       // tournament over 32-wide block columns with MFMA updates (k_bj_*); false: single columns (k_bp_step)
+  DevBuf<real> Qbuf, Sbuf;   // blocked: per (block, block-column pair) the 64 x 64 factor Q and rotated subproblem S'
+  DevBuf<int> Qflag;         // ... and whether the pair's inner sweep rotated at all
   void reset_warm_start() { calls = 0; have_basis = false; }
 
   // pk: signed orders of all PSD blocks (negative = complex embedding order); blocks above lds_kmax are taken
@@ -440,7 +694,17 @@ struct BigPsd {
     }
     nbig = (int)ids.size();
     if (!nbig) return;
-    ld = (kmax + 1) & ~1;
+    blocked = true;
+    if (const char *e = getenv("SCS_AMD_PSD_BLOCKED")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
+    ld = blocked ? (kmax + BJ_W - 1) / BJ_W * BJ_W : (kmax + 1) & ~1;
+    if (blocked) {
+      const size_t npmax = (size_t)ld / BJ_W;
+      Qbuf.alloc((size_t)nbig * npmax * BJ_W * BJ_W);
+      Sbuf.alloc((size_t)nbig * npmax * BJ_W * BJ_W);
+      Qflag.alloc((size_t)nbig * npmax);
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bj_inner), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BJ_INNER_LDS));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bj_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BJ_UPDATE_LDS));
+    }
     id.alloc(ids.size());
     id.upload(ids.data(), ids.size(), st);
     A.alloc((size_t)nbig * ld * ld);
@@ -469,7 +733,7 @@ struct BigPsd {
     ++calls;
     const size_t mat_bytes = (size_t)nbig * ld * ld * sizeof(real);
     hipLaunchKernelGGL(k_bp_set_kraw, dim3((nbig + 63) / 64), dim3(64), 0, st, B);
-    hipLaunchKernelGGL(k_bp_unpack, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B, x, warm ? 0 : 1);
+    hipLaunchKernelGGL(k_bp_unpack, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B, x, warm ? 0 : 1, blocked ? 1 : 0);
     if (warm) {
       const long long T16 = (ld + 15) / 16;
       const int g_mm = (int)std::min<long long>((T16 * T16 + 3) / 4, 8192);
@@ -482,9 +746,20 @@ struct BigPsd {
     int h_rem = nbig;
     long long gstep = 0; // launches so far: the copy of A a block is in alternates with the steps IT took (ctl.cur)
     const long long sweeps_before = sweeps_total;
+    const int nbc_max = ld / BJ_B, npmax = ld / BJ_W;
+    const int g_upd = npmax * npmax + npmax * (ld / BJ_W); // A tiles + V tiles of the largest block
     for (int sweep = 0; sweep < PSD_MAX_SWEEPS && h_rem > 0; ++sweep) {
-      for (int step = 0; step < ld - 1; ++step, ++gstep)
-        hipLaunchKernelGGL(k_bp_step, dim3(g_step, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1) | (step << 1));
+      if (blocked) {
+        for (int step = 0; step < nbc_max - 1; ++step, ++gstep) {
+          const int arg = (int)(gstep & 1) | (step << 1);
+          hipLaunchKernelGGL(k_bj_inner, dim3(npmax, nbig), dim3(BJ_INNER_THREADS), BJ_INNER_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, arg);
+          hipLaunchKernelGGL(k_bj_update, dim3(g_upd, nbig), dim3(BP_THREADS), BJ_UPDATE_LDS, st, B, (const real *)Qbuf.p,
+                             (const real *)Sbuf.p, (const int *)Qflag.p, npmax, arg);
+        }
+      } else {
+        for (int step = 0; step < ld - 1; ++step, ++gstep)
+          hipLaunchKernelGGL(k_bp_step, dim3(g_step, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1) | (step << 1));
+      }
       hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p);
       HIP_CHECK(hipMemcpyAsync(&h_rem, remaining.p, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));

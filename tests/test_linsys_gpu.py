@@ -171,37 +171,3 @@ def test_small_n_very_tall_matrix_with_wave_rows_layout(monkeypatch):
         ref.scs_free_lin_sys_work(wr)
         for k, o in outs.items():
             assert np.abs(o - xr).max() <= 1e-8 * np.abs(xr).max(), k
-
-
-@pytest.mark.parametrize("n,m,col_nnz", [(3001, 7000, 9), (20000, 50000, 10), (300001, 600000, 6)])
-def test_fused_update_direction_kernel_is_bit_identical(monkeypatch, n, m, col_nnz):
-    """k_cg_updir (update + direction behind one grid barrier, p and z in registers across it; linsys.hip) against the
-    two-kernel path: same lane -> chunk mapping and the same fixed-order reductions, so every solve returns the same
-    bits -- over the graph-replayed loop (nnz <= 2e6), the eagerly launched one, an n that is not a multiple of the
-    vector width, several chunks per lane, and a second solve on the same workspace (the barrier's epoch counter
-    carries over)."""
-    amd = capi.load("libscsamd_linsys.so")
-    T = amd._scs_types
-    rng = np.random.default_rng(n)
-    A = probgen.random_csc(m, n, col_nnz, seed=3) if n < 100000 else None
-    if A is None:
-        from scs_amd import problems
-        A = problems.random_cone_prob(n, m, col_nnz, dict(l=m), seed=3)["A"]
-    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
-    dr = probgen.diag_r(n, m, z=m // 10)
-    b1, b2 = rng.uniform(-1, 1, n + m), rng.uniform(-1, 1, n + m)
-    s = rng.uniform(-1, 1, n) * 0.1
-    res = {}
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("SCS_AMD_CGFUSE", fuse)
-        w = amd.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
-        assert w
-        o1, o2 = b1.copy(), b2.copy()
-        assert amd.scs_solve_lin_sys(w, o1.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp), 1e-10) == 0
-        assert amd.scs_solve_lin_sys(w, o2.ctypes.data_as(T.fp), None, 1e-7) == 0
-        st = T.ScsAmdStats()
-        amd.scs_amd_linsys_get_stats(w, C.byref(st))
-        amd.scs_free_lin_sys_work(w)
-        res[fuse] = (o1, o2, st.cg_iters)
-    assert res["0"][2] == res["1"][2] and res["0"][2] > 20
-    assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
