@@ -9,3 +9,5 @@ export TMPDIR=/tmp
 CASES="100x32,128x32,200x16,256x8,512x2,1024x1"
 timeout 600 python scripts/bench_psd_sizes.py --cases $CASES > $OUT/psd_sizes_blocked.jsonl 2> $OUT/psd_sizes_blocked.err; cat $OUT/psd_sizes_blocked.jsonl
 SCS_AMD_PSD_BLOCKED=0 timeout 600 python scripts/bench_psd_sizes.py --cases $CASES > $OUT/psd_sizes_columns.jsonl 2> $OUT/psd_sizes_columns.err; cat $OUT/psd_sizes_columns.jsonl
+( timeout 600 python -m pytest tests/test_linsys_gpu.py tests/test_cones_exp_pow_gpu.py -q --timeout 600 ) > $OUT/pytest_linsys.log 2>&1; tail -5 $OUT/pytest_linsys.log
+timeout 900 python scripts/bench_locality.py > $OUT/locality.jsonl 2> $OUT/locality.err; cat $OUT/locality.jsonl

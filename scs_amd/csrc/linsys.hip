@@ -636,14 +636,20 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
     const int g = wd.grid();
     const size_t lds = wd.lds_bytes();
     WaveView v = wd.view();
+#define WR_LAUNCH(E)                                                                                                   \
+  do {                                                                                                                 \
+    if (wd.pipelined) hipLaunchKernelGGL((csr_wave_kernel<E, true>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
+    else hipLaunchKernelGGL((csr_wave_kernel<E, false>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows);             \
+  } while (0)
     switch (epi) {
-    case EPI_PLAIN: hipLaunchKernelGGL(csr_wave_kernel<EPI_PLAIN>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
-    case EPI_DIV: hipLaunchKernelGGL(csr_wave_kernel<EPI_DIV>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
-    case EPI_GP: hipLaunchKernelGGL(csr_wave_kernel<EPI_GP>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
-    case EPI_ACC: hipLaunchKernelGGL(csr_wave_kernel<EPI_ACC>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
-    case EPI_NEGDIV: hipLaunchKernelGGL(csr_wave_kernel<EPI_NEGDIV>, dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); break;
+    case EPI_PLAIN: WR_LAUNCH(EPI_PLAIN); break;
+    case EPI_DIV: WR_LAUNCH(EPI_DIV); break;
+    case EPI_GP: WR_LAUNCH(EPI_GP); break;
+    case EPI_ACC: WR_LAUNCH(EPI_ACC); break;
+    case EPI_NEGDIV: WR_LAUNCH(EPI_NEGDIV); break;
     default: throw HipError("scs_amd: bad spmv epilogue");
     }
+#undef WR_LAUNCH
     if (sample) spmv_timer.stop(slot, stream);
     n_spmv++;
     return;
@@ -710,6 +716,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     At.wave = new WaveRowsDev();
     At.wave->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
     phase("wave-rows At");
+    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A' gathers: %.3f distinct lines per entry -> %s stream\n", At.wave->lines_per_entry, At.wave->pipelined ? "pipelined" : "plain");
   }
   {
     std::vector<int> Cp_own, Ci_own;
@@ -730,6 +737,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
       A.wave = new WaveRowsDev();
       A.wave->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
       phase("wave-rows A");
+      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream\n", A.wave->lines_per_entry, A.wave->pipelined ? "pipelined" : "plain");
     }
   }
   has_P = P_csc != nullptr;

@@ -48,7 +48,40 @@ __device__ __forceinline__ void lds_add(real *p, real v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int EPI>
+// one lane's 4 consecutive entries of a 256-entry chunk: one 16-byte load of packed words, 16-byte loads of values
+struct WrChunk {
+  uint4 w;
+  real v[4];
+};
+__device__ __forceinline__ WrChunk wr_load(const WaveView &A, int eb) {
+  WrChunk c;
+  c.w = *reinterpret_cast<const uint4 *>(A.wrd + eb);
+  if (sizeof(real) == 8) {
+    const double2 va = *reinterpret_cast<const double2 *>(A.val + eb), vb = *reinterpret_cast<const double2 *>(A.val + eb + 2);
+    c.v[0] = (real)va.x; c.v[1] = (real)va.y; c.v[2] = (real)vb.x; c.v[3] = (real)vb.y;
+  } else {
+    const float4 va = *reinterpret_cast<const float4 *>(A.val + eb);
+    c.v[0] = (real)va.x; c.v[1] = (real)va.y; c.v[2] = (real)va.z; c.v[3] = (real)va.w;
+  }
+  return c;
+}
+__device__ __forceinline__ void wr_consume(const WaveView &A, const WrChunk &c, const real *__restrict__ x, real *acc, int eb, int t,
+                                           unsigned cmask) {
+  const unsigned w[4] = {c.w.x, c.w.y, c.w.z, c.w.w};
+  real xx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xx[i] = eb + i < t ? x[w[i] & cmask] : (real)0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (eb + i < t) lds_add(acc + (w[i] >> A.cbits), c.v[i] * xx[i]);
+}
+
+// PIPE: the next chunk's stream loads are in flight while the current chunk gathers and accumulates.  Chosen per matrix
+// (WaveRowsDev::pipelined): it pays when the gathers of a unit share cache lines (matrices with column locality: the
+// gathers are L1 hits, the product is the 12 B/nnz stream and wants more bytes in flight), and it costs when every gather
+// is its own line fill (the uniformly random matrices of the headline benchmark: 72 / 78 us vs 68 / 72 -- more HBM loads
+// queue ahead of the gathers in the CU's in-order memory path, profiles/r2_g4_lab.md).
+template <int EPI, bool PIPE>
 __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
                                                             const int *skip, int accrows) {
   if (skip && *skip) return;
@@ -62,26 +95,23 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
     const int r0 = A.urow[u], nr = A.urow[u + 1] - r0;
     const int s = A.useg[2 * u], t = A.useg[2 * u + 1];
     for (int k = lane; k < nr; k += 64) acc[k] = 0;
-    // a lane owns 4 consecutive entries of every 256-entry chunk: one 16-byte load of packed words and
-    // 16-byte loads of values (3 stream instructions per chunk instead of 8; unit starts are 4-aligned)
-    for (int e0 = s; e0 < t; e0 += 256) {
-      const int eb = e0 + lane * 4;
-      const uint4 wq = *reinterpret_cast<const uint4 *>(A.wrd + eb);
-      real v[4];
-      if (sizeof(real) == 8) {
-        const double2 va = *reinterpret_cast<const double2 *>(A.val + eb), vb = *reinterpret_cast<const double2 *>(A.val + eb + 2);
-        v[0] = (real)va.x; v[1] = (real)va.y; v[2] = (real)vb.x; v[3] = (real)vb.y;
-      } else {
-        const float4 va = *reinterpret_cast<const float4 *>(A.val + eb);
-        v[0] = (real)va.x; v[1] = (real)va.y; v[2] = (real)va.z; v[3] = (real)va.w;
+    // a lane owns 4 consecutive entries of every 256-entry chunk (3 stream instructions per chunk instead of 8; unit
+    // starts are 4-aligned)
+    if (PIPE) {
+      WrChunk cur = wr_load(A, s + lane * 4); // (an empty unit reads the padding behind its start: harmless)
+      for (int e0 = s; e0 < t; e0 += 256) {
+        const bool more = e0 + 256 < t; // uniform
+        WrChunk nxt = cur;
+        if (more) nxt = wr_load(A, e0 + 256 + lane * 4);
+        wr_consume(A, cur, x, acc, e0 + lane * 4, t, cmask);
+        cur = nxt;
       }
-      const unsigned w[4] = {wq.x, wq.y, wq.z, wq.w};
-      real xx[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xx[i] = eb + i < t ? x[w[i] & cmask] : (real)0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (eb + i < t) lds_add(acc + (w[i] >> A.cbits), v[i] * xx[i]);
+    } else {
+      for (int e0 = s; e0 < t; e0 += 256) {
+        const int eb = e0 + lane * 4;
+        const WrChunk c = wr_load(A, eb);
+        wr_consume(A, c, x, acc, eb, t, cmask);
+      }
     }
     for (int k = lane; k < nr; k += 64) {
       const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
@@ -103,6 +133,8 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
 
 struct WaveRowsDev {
   bool built = false;
+  bool pipelined = false;      // software-pipelined stream (csr_wave_kernel<.., true>): matrices whose gathers share lines
+  double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
   DevBuf<int> urow, useg;
   DevBuf<unsigned> wrd;
@@ -205,6 +237,22 @@ struct WaveRowsDev {
           hw[qq] = (unsigned)hidx[k] | ((unsigned)(rr - ur[u]) << cbits);
           hv[qq] = hval[k];
         }
+    }
+    { // column locality: how many distinct lines of the gathered vector does a unit touch per entry?
+      const int lshift = sizeof(real) == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
+      std::vector<int> stamp(((size_t)cols >> lshift) + 2, -1);
+      long long distinct = 0;
+      for (int u = 0; u < nunit; ++u)
+        for (int k = hptr[ur[u]]; k < hptr[ur[u + 1]]; ++k) {
+          int &st = stamp[(size_t)hidx[k] >> lshift];
+          if (st != u) {
+            st = u;
+            ++distinct;
+          }
+        }
+      lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
+      pipelined = lines_per_entry < 0.5;
+      if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = atoi(e) != 0; // tests / measurements force either
     }
     urow.alloc(ur.size());
     useg.alloc(us.size());

@@ -171,3 +171,40 @@ def test_small_n_very_tall_matrix_with_wave_rows_layout(monkeypatch):
         ref.scs_free_lin_sys_work(wr)
         for k, o in outs.items():
             assert np.abs(o - xr).max() <= 1e-8 * np.abs(xr).max(), k
+
+
+def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(monkeypatch, capfd):
+    """A matrix with column locality (scs_amd/problems.py banded_rows): WaveRowsDev::build measures < 0.5 distinct
+    lines of the gathered vector per entry and picks the software-pipelined instantiation of csr_wave_kernel; same
+    answers as the reference backend and as the plain instantiation (forced)."""
+    from scs_amd import problems
+    amd = capi.load("libscsamd_linsys.so")
+    from oracle import pyoracle
+    ref = pyoracle.load_ref() if pyoracle.ref_available() else None
+    n, m = 40000, 80000
+    A = problems.random_cone_prob(n, m, 8, dict(l=m), seed=13, band=1024)["A"]
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
+    dr = probgen.diag_r(n, m, z=m // 10)
+    rng = np.random.default_rng(4)
+    b = rng.uniform(-1, 1, n + m)
+    s = rng.uniform(-1, 1, n)
+    monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")
+    monkeypatch.setenv("SCS_AMD_DEBUG", "1")
+    outs = []
+    for pipe in (None, "0", "1"):
+        if pipe is None:
+            monkeypatch.delenv("SCS_AMD_WR_PIPE", raising=False)
+        else:
+            monkeypatch.setenv("SCS_AMD_WR_PIPE", pipe)
+        w, out = _solve_with(amd, prob.matA, None, dr, b, s, 1e-12)
+        amd.scs_free_lin_sys_work(w)
+        outs.append(out)
+        if pipe is None:
+            err = capfd.readouterr().err
+            assert err.count("-> pipelined stream") == 2, err[-800:]   # both orientations detected the locality
+    assert np.array_equal(outs[0], outs[2])                            # auto == forced pipelined
+    assert np.array_equal(outs[1], outs[2])                            # same entry order: the two instantiations agree bit for bit
+    if ref is not None:
+        wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
+        ref.scs_free_lin_sys_work(wr)
+        assert np.abs(outs[0] - xr).max() <= 1e-8 * np.abs(xr).max()
