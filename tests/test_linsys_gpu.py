@@ -191,7 +191,7 @@ def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(mon
     monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")
     monkeypatch.setenv("SCS_AMD_DEBUG", "1")
     outs = []
-    for pipe in (None, "0", "1"):
+    for pipe in (None, "0", "1", "2"):
         if pipe is None:
             monkeypatch.delenv("SCS_AMD_WR_PIPE", raising=False)
         else:
@@ -202,8 +202,8 @@ def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(mon
         if pipe is None:
             err = capfd.readouterr().err
             assert err.count("-> pipelined stream") == 2, err[-800:]   # both orientations detected the locality
-    assert np.array_equal(outs[0], outs[2])                            # auto == forced pipelined
-    assert np.array_equal(outs[1], outs[2])                            # same entry order: the two instantiations agree bit for bit
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)                              # same entry order: every instantiation agrees bit for bit
     if ref is not None:
         wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
         ref.scs_free_lin_sys_work(wr)
