@@ -76,13 +76,13 @@ __device__ __forceinline__ void wr_consume(const WaveView &A, const WrChunk &c, 
     if (eb + i < t) lds_add(acc + (w[i] >> A.cbits), c.v[i] * xx[i]);
 }
 
-// PIPE = 1 / 2: the stream loads of the next one / two chunks are in flight while the current chunk gathers and
-// accumulates.  Chosen per matrix (WaveRowsDev::pipelined) from the measured line sharing of its gathers: with column
-// locality the gathers are L1 / L2 hits, the product is the 12 B/nnz stream and wants more bytes in flight (band of 4096
-// rows at the headline sizes: 51.5 -> 46.2 us per product with one chunk ahead, profiles/r3_locality.md); when every
-// gather is its own line fill (the uniformly random matrices of the headline benchmark) there is nothing to win (69.1 vs
-// 69.6 us) and deeper queues lose (72 / 78 us, profiles/r2_g4_lab.md: more HBM loads ahead of the gathers in the CU's
-// in-order memory path).
+// PIPE = 1: the stream loads of the next chunk are in flight while the current chunk gathers and accumulates.  Chosen
+// per matrix (WaveRowsDev::pipelined) from the measured line sharing of its gathers: with column locality the gathers are
+// L1 / L2 hits, the product is the 12 B/nnz stream and wants more bytes in flight (headline sizes, columns confined to a
+// band of 1024 / 4096 / 65536 rows: 45.8 -> 39.8, 51.3 -> 46.3, 68.8 -> 65.3 us per product; profiles/r3_locality_v2.jsonl);
+// when every gather is its own line fill (the uniformly random matrices of the headline benchmark) there is nothing to
+// win (69.1 vs 69.6 us), and two chunks ahead lose everywhere (42.4 / 51.7 / 70.0 us; profiles/r2_g4_lab.md for the
+// random case: more HBM loads queue ahead of the gathers in the CU's in-order memory path).
 template <int EPI, int PIPE>
 __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
                                                             const int *skip, int accrows) {
@@ -99,18 +99,8 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
     for (int k = lane; k < nr; k += 64) acc[k] = 0;
     // a lane owns 4 consecutive entries of every 256-entry chunk (3 stream instructions per chunk instead of 8; unit
     // starts are 4-aligned)
-    if (PIPE == 2) { // two chunks ahead
-      WrChunk cur = wr_load(A, s + lane * 4), nx1 = cur; // (an empty unit reads the padding behind its start: harmless)
-      if (s + 256 < t) nx1 = wr_load(A, s + 256 + lane * 4);
-      for (int e0 = s; e0 < t; e0 += 256) {
-        WrChunk nx2 = nx1;
-        if (e0 + 512 < t) nx2 = wr_load(A, e0 + 512 + lane * 4); // uniform condition
-        wr_consume(A, cur, x, acc, e0 + lane * 4, t, cmask);
-        cur = nx1;
-        nx1 = nx2;
-      }
-    } else if (PIPE == 1) {
-      WrChunk cur = wr_load(A, s + lane * 4);
+    if (PIPE == 1) {
+      WrChunk cur = wr_load(A, s + lane * 4); // (an empty unit reads the padding behind its start: harmless)
       for (int e0 = s; e0 < t; e0 += 256) {
         const bool more = e0 + 256 < t; // uniform
         WrChunk nxt = cur;
@@ -145,7 +135,7 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
 
 struct WaveRowsDev {
   bool built = false;
-  int pipelined = 0;           // chunks of stream kept in flight ahead of the gathers (csr_wave_kernel<.., PIPE>): matrices whose gathers share lines
+  int pipelined = 0;           // 1: one chunk of stream in flight ahead of the gathers (csr_wave_kernel<.., 1>): matrices whose gathers share lines
   double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
   DevBuf<int> urow, useg;
@@ -263,8 +253,8 @@ struct WaveRowsDev {
           }
         }
       lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
-      pipelined = lines_per_entry < 0.25 ? 2 : (lines_per_entry < 0.8 ? 1 : 0);
-      if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = std::max(0, std::min(2, atoi(e))); // tests / measurements force one
+      pipelined = lines_per_entry < 0.8 ? 1 : 0;
+      if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
     }
     urow.alloc(ur.size());
     useg.alloc(us.size());

@@ -191,7 +191,7 @@ def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(mon
     monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")
     monkeypatch.setenv("SCS_AMD_DEBUG", "1")
     outs = []
-    for pipe in (None, "0", "1", "2"):
+    for pipe in (None, "0", "1"):
         if pipe is None:
             monkeypatch.delenv("SCS_AMD_WR_PIPE", raising=False)
         else:
