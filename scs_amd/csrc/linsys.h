@@ -22,15 +22,6 @@ struct CgCtl {
   int cg_done;   // converged (or breakdown): remaining iteration kernels return
   int iters;     // PCG iterations performed (reference counting, private.c:203,216)
   int max_its;   // 10 n (private.c:307): the device stops there even if more iterations were enqueued
-  unsigned epoch; // persistent PCG loop: grid barriers completed so far (monotonic over the workspace's life)
-  unsigned fault; // ... a bounded spin of one of them ran out: the solve is reported as failed
-};
-
-// arrival counter and generation word of the persistent loop's grid barrier (128 bytes apart; monotonic: nothing is
-// re-initialised between launches)
-struct PcgBarrierWords {
-  unsigned count[32];
-  unsigned gen[32];
 };
 
 struct LinSys {
@@ -40,9 +31,6 @@ struct LinSys {
   bool has_P = false;
   bool use_fused = false; // whole solve in one workgroup (small systems)
   bool use_cg2 = false;   // two launches per CG iteration (n <= CG2_N_MAX): k_cg2_a + transposed product
-  bool use_persist = false; // the whole PCG loop in ONE launch of <= 64 co-resident workgroups (k_pcg_persist): latency-bound sizes
-  int persist_grid = 0;
-  DevBuf<PcgBarrierWords> pbar;
 
   CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector
   CsrDev A;  // CSR(A): m rows, gathers an n-vector

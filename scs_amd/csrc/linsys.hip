@@ -479,165 +479,10 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg2_a(CsrView A, const real *_
   csr_stream_blocks<EPI_DIV>(A, pl, tmp, e, prod, red, blockIdx.x, gridDim.x, dot);
 }
 
-// ----------------------------------------------------------------------------
-// Latency-bound sizes: the WHOLE iteration loop of pcg (private.c:174-217) in ONE launch.  Below ~1e5 nonzeros a CG
-// iteration is four kernels of a few microseconds of work each, every one waiting ~3.5 us for the data the previous
-// one wrote on other CUs; here <= 64 co-resident workgroups run the four phases of an iteration
-// back to back and meet at a grid barrier between them (one arrival counter, one generation word: with this few
-// arrivers a flat barrier is a couple of L2 round trips), the loop exits on the device at convergence -- no batches
-// enqueued past it, no host read-back per batch.
-// The arithmetic is that of the four-kernel path to the bit: a workgroup here plays the "virtual" workgroups v = g,
-// g + G, ... of csr_stream_kernel<DIV> (grid gA), csr_stream_kernel<GP> (grid gAt: one p'Gp partial per virtual
-// workgroup), k_cg_update and k_cg_direction (grid gv: one z'r / |r| partial per virtual workgroup) with the same lane ->
-// row / chunk mapping, and every workgroup re-reduces the partial arrays in the same fixed order, so alpha, beta and the
-// stopping decision are identical everywhere (the exit is uniform without anybody re-reading a control word).
-// Co-residency: 64 workgroups of 256 lanes fit the chip ~30 times over; every spin is bounded, a spin that runs out
-// raises ctl->fault and the host reports a failed solve.
-// ----------------------------------------------------------------------------
-constexpr int PERSIST_MAX_WG = 64;
-constexpr long long PERSIST_MAX_NNZ = 400000; // above this a CG iteration is bandwidth, not latency (measured: DESIGN.md section 6)
-
-__device__ __forceinline__ bool pcg_grid_barrier(PcgBarrierWords *bar, unsigned target_gen, CgCtl *ctl) {
-  __shared__ int passed;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // every wave: its stores are in L2 / written back before the arrival counts
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned a = __hip_atomic_fetch_add(&bar->count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a + 1u == target_gen * gridDim.x) __hip_atomic_store(&bar->gen[0], target_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 0;
-    for (unsigned spin = 0; spin < (1u << 22); ++spin) {
-      if (__hip_atomic_load(&bar->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target_gen) {
-        ok = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (!ok) __hip_atomic_store(&ctl->fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    passed = ok;
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // what the other workgroups wrote is re-read from beyond this CU's caches
-  return passed != 0;
-}
-
-__global__ __launch_bounds__(SCSAMD_BLOCK) void k_pcg_persist(CsrView A, CsrView At, const real *__restrict__ ry,
-                                                              const real *__restrict__ rx, const real *__restrict__ M, real *x,
-                                                              real *r, real *p, real *Gp, real *z, real *tmp, real *part_pgp,
-                                                              real *part_ztr, real *part_max, CgCtl *ctl, PcgBarrierWords *bar,
-                                                              int gA, int gAt, int gv, int n) {
-  __shared__ real prod[NNZ_PER_BLOCK];
-  __shared__ real red[SCSAMD_BLOCK / SCSAMD_WAVE];
-  const int tid = threadIdx.x, G = gridDim.x;
-  if (ctl->cg_done) return; // zero right-hand side or converged at the start (k_rhs_prep / k_cg_start): uniform
-  unsigned gen = ctl->epoch;
-  real ztr_prev = ctl->ztr[0];
-  const real tol = ctl->tol;
-  const int max_its = ctl->max_its;
-  int iters = 0;
-  real ztr = ztr_prev, nr = 0;
-  const int nv = n / RVW, gs = gv * SCSAMD_BLOCK;
-  for (;;) {
-    // ---- tmp = R_y^-1 A p
-    for (int v = blockIdx.x; v < gA; v += G) {
-      EpiArgs e{ry, nullptr, nullptr, nullptr};
-      real dot = 0;
-      csr_stream_blocks<EPI_DIV>(A, p, tmp, e, prod, red, v, gA, dot);
-    }
-    if (!pcg_grid_barrier(bar, ++gen, ctl)) return;
-    // ---- Gp = R_x p + A' tmp, one p'Gp partial per virtual workgroup
-    for (int v = blockIdx.x; v < gAt; v += G) {
-      EpiArgs e{rx, p, nullptr, nullptr};
-      real dot = 0;
-      csr_stream_blocks<EPI_GP>(At, tmp, Gp, e, prod, red, v, gAt, dot);
-      dot = block_sum(dot, red);
-      if (tid == 0) part_pgp[v] = dot;
-    }
-    if (!pcg_grid_barrier(bar, ++gen, ctl)) return;
-    // ---- alpha; x += alpha p; r -= alpha Gp; z = M r; partials of z'r, |r|_inf (k_cg_update)
-    real psum = 0;
-    for (int i = tid; i < gAt; i += SCSAMD_BLOCK) psum += part_pgp[i];
-    const real pgp = block_sum(psum, red);
-    const real alpha = ztr_prev / pgp;
-    for (int v = blockIdx.x; v < gv; v += G) {
-      const int gtid = v * SCSAMD_BLOCK + tid;
-      real zt = 0, mx = 0;
-      for (int iv = gtid; iv < nv; iv += gs) {
-        const rvec P = ldv(p, iv), Gq = ldv(Gp, iv), Mv = ldv(M, iv);
-        rvec X = ldv(x, iv), R = ldv(r, iv), Z;
-#pragma unroll
-        for (int e = 0; e < RVW; ++e) {
-          X.v[e] += alpha * P.v[e];
-          const real ri = R.v[e] + (-alpha) * Gq.v[e];
-          R.v[e] = ri;
-          const real zi = ri * Mv.v[e];
-          Z.v[e] = zi;
-          zt += zi * ri;
-          const real a = absval(ri);
-          mx = a > mx ? a : mx;
-        }
-        stv(x, iv, X);
-        stv(r, iv, R);
-        stv(z, iv, Z);
-      }
-      for (int i = nv * RVW + gtid; i < n; i += gs) {
-        const real pi = p[i], gi = Gp[i];
-        x[i] += alpha * pi;
-        const real ri = r[i] + (-alpha) * gi;
-        r[i] = ri;
-        const real zi = ri * M[i];
-        z[i] = zi;
-        zt += zi * ri;
-        const real a = absval(ri);
-        mx = a > mx ? a : mx;
-      }
-      zt = block_sum(zt, red);
-      mx = block_max(mx, red);
-      if (tid == 0) {
-        part_ztr[v] = zt;
-        part_max[v] = mx;
-      }
-    }
-    if (!pcg_grid_barrier(bar, ++gen, ctl)) return;
-    // ---- stop test, beta, p = z + beta p (k_cg_direction)
-    real zs = 0, ms = 0;
-    for (int i = tid; i < gv; i += SCSAMD_BLOCK) {
-      zs += part_ztr[i];
-      const real vv = part_max[i];
-      ms = vv > ms ? vv : ms;
-    }
-    ztr = block_sum(zs, red);
-    nr = block_max(ms, red);
-    const bool conv = nr < tol;
-    const bool brk = !conv && ztr_prev == (real)0;
-    if (!conv && !brk) {
-      const real beta = ztr / ztr_prev;
-      for (int v = blockIdx.x; v < gv; v += G) {
-        const int gtid = v * SCSAMD_BLOCK + tid;
-        for (int iv = gtid; iv < nv; iv += gs) {
-          const rvec Z = ldv(z, iv);
-          rvec P = ldv(p, iv);
-#pragma unroll
-          for (int e = 0; e < RVW; ++e) P.v[e] = Z.v[e] + beta * P.v[e];
-          stv(p, iv, P);
-        }
-        for (int i = nv * RVW + gtid; i < n; i += gs) p[i] = z[i] + beta * p[i];
-      }
-    }
-    if (!brk) ++iters; // converged at i -> i + 1; breakdown returns i (private.c:203,216)
-    ztr_prev = ztr;
-    if (conv || brk || iters >= max_its) break; // the same decision in every workgroup
-    if (!pcg_grid_barrier(bar, ++gen, ctl)) return;
-  }
-  if (blockIdx.x == 0 && tid == 0) {
-    ctl->ztr[0] = ztr;
-    ctl->ztr[1] = ztr;
-    ctl->norm_r = nr;
-    ctl->iters = iters;
-    ctl->cg_done = 1;
-    ctl->epoch = gen; // (every workgroup read the old value before its first barrier of this launch)
-  }
-}
-
+// (The whole iteration loop in ONE persistent launch of <= 64 co-resident workgroups with grid barriers between the phases was built in
+// round 3, bit-identical to the kernel-per-phase path, and measured slower at every size -- 19.9 vs 16.6 us per CG iteration at n = 1000,
+// 39.5 vs 21.1 at n = 2e4: an agent-scope release / acquire pair costs more here than a dependent kernel boundary;
+// profiles/r3_persistent_pcg.md.)
 // ----------------------------------------------------------------------------
 // Tiny systems: the WHOLE scs_solve_lin_sys (private.c:284-324) in one launch of one
 // 1024-lane workgroup.  Below a few thousand nonzeros a CG iteration is four launches of
@@ -951,13 +796,6 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     const bool no_wave = !(A.wave && A.wave->built) && !(At.wave && At.wave->built);
     use_cg2 = !use_fused && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
     if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
-    // the whole PCG loop in one launch (k_pcg_persist) while a CG iteration is latency, not bandwidth
-    use_persist = !use_fused && !has_P && no_wave && nnzA <= PERSIST_MAX_NNZ;
-    if (const char *e = getenv("SCS_AMD_PERSIST")) use_persist = atoi(e) != 0 && !use_fused && !has_P && no_wave;
-    if (use_persist) {
-      persist_grid = std::max(1, std::min(PERSIST_MAX_WG, std::max(std::max(A.grid(), At.grid()), vec_grid(n))));
-      pbar.alloc(1);
-    }
     if (use_cg2) {
       p2.alloc(n);
       r2.alloc(n);
@@ -1166,26 +1004,6 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
                      partB.p, c);
   hipLaunchKernelGGL(k_cg_start, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, partA.p, partB.p, gv, c);
 
-  if (use_persist && !profiling) { // the loop runs and exits on the device: one launch, one read-back
-    hipLaunchKernelGGL(k_pcg_persist, dim3(persist_grid), dim3(SCSAMD_BLOCK), 0, stream, A.view(), At.view(), ry.p, rx.p, M.p, b, r.p,
-                       p.p, Gp.p, z.p, tmp.p, partA.p, partB.p, partB.p + PART_CAP / 2, c, pbar.p, A.grid(), At.grid(), gv, n);
-    EpiArgs e{ry.p, nullptr, nullptr, nullptr};
-    launch_spmv(EPI_NEGDIV, A, b, b + n, e, &c->zero_rhs); // y = R_y^-1 (A x - r_y)   (private.c:313-317)
-    HIP_CHECK(hipMemcpyAsync(hctl.p, c, sizeof(CgCtl), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipGetLastError());
-    if (profiling) cg_timer.stop(cg_slot, stream);
-    if (hctl.p->fault) throw HipError("scs_amd: grid barrier of the persistent PCG loop timed out (workgroups not co-resident)");
-    if (debug)
-      fprintf(stderr, "[scs_amd pcg persistent] iters=%d zero=%d |r|=%.3e tol=%.3e |b|=%.3e grid=%d\n", hctl.p->iters, hctl.p->zero_rhs,
-              (double)hctl.p->norm_r, (double)hctl.p->tol, (double)hctl.p->rhs_norm, persist_grid);
-    const int pits = hctl.p->iters;
-    n_matvecs += pits;
-    last_its = pits;
-    tot_cg_its += pits;
-    n_solves++;
-    return pits;
-  }
   // ---- iteration batches ---------------------------------------------------
   const long long max_its = 10LL * n; // private.c:307
   long long it = 0;

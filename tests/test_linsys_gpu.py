@@ -208,47 +208,3 @@ def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(mon
         wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
         ref.scs_free_lin_sys_work(wr)
         assert np.abs(outs[0] - xr).max() <= 1e-8 * np.abs(xr).max()
-
-
-@pytest.mark.parametrize("n,m,col_nnz", [(1000, 3000, 32), (3001, 7000, 9), (20000, 50000, 10), (37, 4000, 30)])
-def test_persistent_pcg_loop_is_bit_identical_to_the_kernel_per_phase_path(monkeypatch, n, m, col_nnz):
-    """k_pcg_persist (the whole iteration loop in one launch of <= 64 co-resident workgroups, grid barriers between the
-    phases; linsys.hip) plays the virtual workgroups of the four kernels it replaces with the same lane -> row / chunk
-    mapping and the same fixed-order reductions: every solve must return the same bits as the kernel-per-phase path --
-    configs[0]'s shape, an n that is not a multiple of the vector width, the largest size it is used at, a very tall
-    matrix, warm and cold starts, a second solve on the same workspace (the barrier generation carries over), and a
-    shrunken vector grid (several virtual workgroups per lane stride)."""
-    amd = capi.load("libscsamd_linsys.so")
-    T = amd._scs_types
-    rng = np.random.default_rng(n)
-    A = probgen.random_csc(m, n, col_nnz, seed=3)
-    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
-    dr = probgen.diag_r(n, m, z=m // 10)
-    b1, b2 = rng.uniform(-1, 1, n + m), rng.uniform(-1, 1, n + m)
-    s = rng.uniform(-1, 1, n) * 0.1
-    res = {}
-    for persist, vgrid in (("0", None), ("1", None), ("1", "3")):
-        monkeypatch.setenv("SCS_AMD_PERSIST", persist)
-        monkeypatch.setenv("SCS_AMD_CG2", "0")
-        if vgrid:
-            monkeypatch.setenv("SCS_AMD_VEC_MAX_GRID", vgrid)
-        else:
-            monkeypatch.delenv("SCS_AMD_VEC_MAX_GRID", raising=False)
-        w = amd.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
-        assert w
-        o1, o2, o3 = b1.copy(), b2.copy(), np.full(n + m, 1e-14)
-        assert amd.scs_solve_lin_sys(w, o1.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp), 1e-10) == 0
-        assert amd.scs_solve_lin_sys(w, o2.ctypes.data_as(T.fp), None, 1e-6) == 0
-        assert amd.scs_solve_lin_sys(w, o3.ctypes.data_as(T.fp), None, 1e-6) == 0  # zero right-hand side: the loop is skipped
-        st = T.ScsAmdStats()
-        amd.scs_amd_linsys_get_stats(w, C.byref(st))
-        amd.scs_free_lin_sys_work(w)
-        res[(persist, vgrid)] = (o1, o2, o3, st.cg_iters)
-    base = res[("0", None)]
-    assert base[3] > 10 and np.all(base[2] == 0.0)
-    got = res[("1", None)]
-    assert got[3] == base[3]
-    assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]) and np.array_equal(got[2], base[2])
-    # a different vector grid changes the shape of the partial sums (rounding-level), not the answer
-    alt = res[("1", "3")]
-    assert np.abs(alt[0] - base[0]).max() <= 1e-9 * np.abs(base[0]).max()
