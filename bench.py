@@ -36,7 +36,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet (fp64 matrix = fp64 vector); the guide lists no fp64 figure
-PMC_TRAFFIC_JSON = "r2_pmc_traffic.json"  # committed PMC passes the static roofline.traffic field is read from
+# committed PMC passes the static roofline.traffic field is read from: the newest round's that exists
+PMC_TRAFFIC_JSON = next((f for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
+                        "r2_pmc_traffic.json")
 
 
 def parse():
