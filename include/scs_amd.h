@@ -253,6 +253,17 @@ typedef struct {
 
 void scs_amd_linsys_get_stats(const ScsLinSysWork *w, ScsAmdStats *out);
 void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on);
+/* Pieces of the operator of linsys/cpu/indirect/private.c:106-119 (`mat_vec`) on DEVICE pointers, for a caller that splits
+ * ONE linear system by rows of A across GPUs (scs_amd/shard.py): the workspace is created by
+ * scs_init_lin_sys_work on a row slab A_r (m_r x n) with diag_r = [R_x / ranks ; R_y of the slab], so that the sum over
+ * ranks of mat_vec is R_x x + A' R_y^-1 A x.  Work is enqueued on the workspace's stream; _sync waits for it.
+ *   mat_vec_dev   y(n)   = diag_r[0..n) .* x + A_r' R_r^-1 A_r x
+ *   mul_a_dev     y(m_r) = A_r x           (src/scs.c:559 uses the same product for the residuals)
+ *   mul_at_dev    x(n)   = A_r' y                                                                                  */
+scs_int scs_amd_linsys_mat_vec_dev(ScsLinSysWork *w, const scs_float *x_dev, scs_float *y_dev);
+scs_int scs_amd_linsys_mul_a_dev(ScsLinSysWork *w, const scs_float *x_dev, scs_float *y_dev);
+scs_int scs_amd_linsys_mul_at_dev(ScsLinSysWork *w, const scs_float *y_dev, scs_float *x_dev);
+scs_int scs_amd_linsys_sync(ScsLinSysWork *w);
 void scs_amd_get_stats(const ScsWork *w, ScsAmdStats *out);
 void scs_amd_set_profiling(ScsWork *w, scs_int on);
 /* scs_solve split in three so a harness can time / inspect an exact range of ADMM

@@ -47,6 +47,6 @@ json.dump({
     "hbm_bytes_per_launch_mean": int(sum(v["hbm_bytes_per_launch"] for v in vals) / len(vals)),
     "algorithmic_bytes_per_launch_mean": 150000004,
     "kernel_avg_us_profiled": prof_us,
-    "kernel_stats_source": f"{stats_md} (rocprofv3 --kernel-trace --stats of the bench command, active launches)",
+    "kernel_stats_source": "rocprofv3 --kernel-trace --stats of the bench command in the same script run (active launches; copied to profiles/ as <round>_bench_kernel_stats.md)",
 }, open(out, "w"), indent=1)
 print(open(out).read())

@@ -17,6 +17,6 @@ cd $R
 python3 scripts/rocpd_stats.py $(ls $OUT/trace/*results.db | head -1) 20 > $OUT/kernel_stats.md 2> $OUT/kernel_stats.err
 python3 scripts/rocpd_pmc.py $(ls $OUT/pmc_fetch/*results.db | head -1) 20 > $OUT/pmc_fetch.md 2>/dev/null
 python3 scripts/rocpd_pmc.py $(ls $OUT/pmc_write/*results.db | head -1) 20 > $OUT/pmc_write.md 2>/dev/null
-python3 scripts/pmc_traffic_json.py $(ls $OUT/pmc_fetch/*results.db | head -1) $(ls $OUT/pmc_write/*results.db | head -1) $OUT/pmc_traffic.json profiles/${ROUND}_bench_kernel_stats.md "round ${ROUND#r}" > /dev/null 2> $OUT/pmc_json.err
+python3 scripts/pmc_traffic_json.py $(ls $OUT/pmc_fetch/*results.db | head -1) $(ls $OUT/pmc_write/*results.db | head -1) $OUT/pmc_traffic.json $OUT/kernel_stats.md "round ${ROUND#r}" > /dev/null 2> $OUT/pmc_json.err
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write   # the databases are large; the summaries are what is kept
 head -12 $OUT/kernel_stats.md | cut -c1-200; cat $OUT/pmc_traffic.json

@@ -141,6 +141,12 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
         lib.scs_amd_linsys_get_stats.argtypes = [C.c_void_p, C.POINTER(T.ScsAmdStats)]
         lib.scs_amd_linsys_set_profiling.restype = None
         lib.scs_amd_linsys_set_profiling.argtypes = [C.c_void_p, scs_int]
+        for nm in ("scs_amd_linsys_mat_vec_dev", "scs_amd_linsys_mul_a_dev", "scs_amd_linsys_mul_at_dev"):
+            fn = getattr(lib, nm)
+            fn.restype = scs_int
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]  # device pointers
+        lib.scs_amd_linsys_sync.restype = scs_int
+        lib.scs_amd_linsys_sync.argtypes = [C.c_void_p]
         lib.scs_amd_device_count.restype = scs_int
         lib.scs_amd_device_count.argtypes = []
         lib.scs_amd_set_device.restype = scs_int

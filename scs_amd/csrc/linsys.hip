@@ -1171,6 +1171,34 @@ void scs_free_lin_sys_work(ScsLinSysWork *w) {
   delete w;
 }
 
+// operator pieces on device pointers (row-sharded systems, scs_amd/shard.py)
+static scs_int with_work(ScsLinSysWork *w, const void *a, const void *b, void (*fn)(LinSys &, const real *, real *)) {
+  if (!w || !a || !b) return -1;
+  try {
+    HIP_CHECK(hipSetDevice(w->device));
+    fn(w->ls, static_cast<const real *>(a), static_cast<real *>(const_cast<void *>(b)));
+    HIP_CHECK(hipGetLastError());
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
+  return 0;
+}
+scs_int scs_amd_linsys_mat_vec_dev(ScsLinSysWork *w, const scs_float *x_dev, scs_float *y_dev) {
+  return with_work(w, x_dev, y_dev, [](LinSys &ls, const real *x, real *y) { ls.mat_vec_dev(x, y, nullptr); });
+}
+scs_int scs_amd_linsys_mul_a_dev(ScsLinSysWork *w, const scs_float *x_dev, scs_float *y_dev) {
+  return with_work(w, x_dev, y_dev, [](LinSys &ls, const real *x, real *y) { ls.mul_A(x, y); });
+}
+scs_int scs_amd_linsys_mul_at_dev(ScsLinSysWork *w, const scs_float *y_dev, scs_float *x_dev) {
+  return with_work(w, y_dev, x_dev, [](LinSys &ls, const real *y, real *x) { ls.mul_At(y, x); });
+}
+scs_int scs_amd_linsys_sync(ScsLinSysWork *w) {
+  if (!w) return -1;
+  if (hipSetDevice(w->device) != hipSuccess) return -1;
+  return hipStreamSynchronize(w->ls.stream) == hipSuccess ? 0 : -1;
+}
+
 void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on) {
   if (w) w->ls.profiling = on != 0;
 }

@@ -1,0 +1,148 @@
+"""ONE linear system split by rows of A across ranks ("intra-problem sharding"; the operator that is
+split is reference linsys/cpu/indirect/private.c:106-119, the solve is :133-324).
+
+Rank r holds the row slab A_r (rows [r0, r1) of A, all n columns) and the matching slab of R_y; every rank holds the
+n-vectors.  The reduced operator is a sum over ranks,
+
+    G x = R_x x + A' R_y^-1 A x = sum_r ( (R_x / N) x + A_r' R_r^-1 A_r x ),
+
+so one PCG iteration is: every rank applies ITS term with the MI355X SpMV kernels (`scs_amd_linsys_mat_vec_dev`, device
+pointers), one all-reduce of an n-vector (RCCL: `torch.distributed` backend "nccl"; gloo in the CPU-hosted tests) forms G p,
+and the level-1 part of the iteration runs redundantly on every rank (so no second collective is needed for alpha / beta).
+The back-substitution y = R_y^-1 (A x - r_y) is local to each slab.
+
+This is the FUNCTIONAL form of the split (torch is plumbing here: device vectors, the collective, the O(n) vector
+algebra); it is not the product path of the benchmark: at n = 1e6 the all-reduce moves 8 MB per CG iteration against
+~170 us of compute, i.e. ~100 us on 7 x 153 GB/s xGMI links -- a split that cannot pay at these sizes.
+It exists for problems that do not fit one GPU's 288 GB, and to have the data-path collective exercised.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def slab(m, world, rank):
+    """rows [r0, r1) of rank `rank`: contiguous, sizes differing by at most one"""
+    base, extra = divmod(m, world)
+    r0 = rank * base + min(rank, extra)
+    return r0, r0 + base + (1 if rank < extra else 0)
+
+
+class ShardedLinSys:
+    """A: scipy CSC (m x n) -- every rank passes the same matrix (or at least its own rows); diag_r = [R_x (n); R_y (m)]."""
+
+    def __init__(self, A, diag_r, dist=None, device="cuda", lib=None):
+        import scipy.sparse as sp
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+        self.world = 1 if dist is None else dist.get_world_size()
+        self.rank = 0 if dist is None else dist.get_rank()
+        self.lib = lib or capi.load("libscsamd_linsys.so")
+        self.T = self.lib._scs_types
+        self.m, self.n = A.shape
+        self.r0, self.r1 = slab(self.m, self.world, self.rank)
+        Ar = sp.csc_matrix(sp.csr_matrix(A)[self.r0:self.r1, :])
+        self.prob = capi.Problem(Ar, np.zeros(self.r1 - self.r0), np.zeros(self.n), dict(l=self.r1 - self.r0), T=self.T)
+        f = self.T.np_float
+        diag_r = np.asarray(diag_r, dtype=f)
+        self.rx = diag_r[:self.n].copy()
+        self.ry = diag_r[self.n + self.r0:self.n + self.r1].copy()
+        local = np.concatenate([self.rx / self.world, self.ry]).astype(f)
+        self.w = self.lib.scs_init_lin_sys_work(C.byref(self.prob.matA), None, local.ctypes.data_as(self.T.fp))
+        if not self.w:
+            raise RuntimeError("scs_init_lin_sys_work failed on the row slab")
+        td = torch.float64 if f is np.float64 else torch.float32
+        self.td = td
+        # Jacobi preconditioner (private.c:50-82): diag(G) = R_x + sum_r diag(A_r' R_r^-1 A_r)
+        Asq = Ar.multiply(Ar)
+        d = torch.tensor(np.asarray(Asq.T @ (1.0 / self.ry)).ravel(), dtype=td, device=device)
+        self._allreduce(d)
+        self.M = 1.0 / (torch.tensor(self.rx, dtype=td, device=device) + d)
+        self.ry_d = torch.tensor(self.ry, dtype=td, device=device)
+        self.allreduce_calls = 0
+        self.cg_iters = 0
+
+    # ---- plumbing -----------------------------------------------------------------------------------------------
+    def _allreduce(self, t):
+        """in-place sum over ranks of a device tensor (RCCL when the group's backend is nccl; gloo goes through the host)"""
+        if self.dist is None:
+            return t
+        if self.dist.get_backend() == "nccl":
+            self.dist.all_reduce(t)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+        return t
+
+    def _call(self, fn, src, dst):
+        self.torch.cuda.synchronize()  # torch's stream and the workspace's stream are different streams: functional form
+        if fn(self.w, src.data_ptr(), dst.data_ptr()) != 0:
+            raise RuntimeError("device operator call failed")
+        if self.lib.scs_amd_linsys_sync(self.w) != 0:
+            raise RuntimeError("stream synchronisation failed")
+
+    def G(self, x):
+        """G x, the same vector on every rank"""
+        y = self.torch.empty_like(x)
+        self._call(self.lib.scs_amd_linsys_mat_vec_dev, x, y)
+        self.allreduce_calls += 1
+        return self._allreduce(y)
+
+    # ---- scs_solve_lin_sys (private.c:284-324) --------------------------------------------------------------------
+    def solve(self, b, s=None, tol=1e-9):
+        """b = [r_x (n); r_y (m)] (host, the same on every rank), s = warm start (n) or None.
+        Returns (x (n), y slab (r1 - r0)) as numpy arrays: x identical on every rank, y the rank's rows."""
+        torch, td, dev, n = self.torch, self.td, self.device, self.n
+        b = np.asarray(b)
+        if np.abs(b).max() <= 1e-12:  # private.c:296-299
+            return np.zeros(n), np.zeros(self.r1 - self.r0)
+        bx = torch.tensor(b[:n], dtype=td, device=dev)
+        by = torch.tensor(b[n + self.r0:n + self.r1], dtype=td, device=dev)
+        t = torch.empty(n, dtype=td, device=dev)
+        self._call(self.lib.scs_amd_linsys_mul_at_dev, by / self.ry_d, t)  # A_r' R_r^-1 r_y
+        bx = bx + self._allreduce(t)
+        if s is not None:
+            x = torch.tensor(np.asarray(s), dtype=td, device=dev)
+            r = bx - self.G(x)
+        else:
+            x = torch.zeros(n, dtype=td, device=dev)
+            r = bx.clone()
+        z = self.M * r
+        ztr = torch.dot(z, r)
+        its = 0
+        if float(r.abs().max()) >= max(tol, 1e-12):  # private.c:163
+            p = z.clone()
+            for its in range(1, 10 * n + 1):  # private.c:174-217
+                Gp = self.G(p)
+                alpha = ztr / torch.dot(p, Gp)
+                x += alpha * p
+                r -= alpha * Gp
+                if float(r.abs().max()) < tol:
+                    break
+                z = self.M * r
+                ztr_prev, ztr = ztr, torch.dot(z, r)
+                if float(ztr_prev) == 0.0:
+                    its -= 1
+                    break
+                p = z + (ztr / ztr_prev) * p
+        self.cg_iters += its
+        ax = torch.empty(self.r1 - self.r0, dtype=td, device=dev)
+        self._call(self.lib.scs_amd_linsys_mul_a_dev, x, ax)
+        y = (ax - by) / self.ry_d  # private.c:313-317
+        return x.cpu().numpy(), y.cpu().numpy()
+
+    def gather_y(self, y_local):
+        """every rank's slab of y in row order (host)"""
+        if self.dist is None:
+            return y_local
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, y_local)
+        return np.concatenate(parts)
+
+    def close(self):
+        if self.w:
+            self.lib.scs_free_lin_sys_work(self.w)
+            self.w = None

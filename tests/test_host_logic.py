@@ -140,3 +140,13 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert iters == [50, 75]  # the stub's ranks converge at different iterations
     # value = all ranks' iterations / the slowest rank's wall time; the window figure is separate
     assert d["value"] > 0 and d["window_it_per_s"] > 0 and abs(d["ms_per_step"] - 2.0) < 2.0
+
+
+def test_row_slabs_of_the_sharded_linear_system_cover_every_row_once():
+    from scs_amd import shard
+    for m, world in ((15001, 2), (10, 3), (7, 8), (1000000, 8)):
+        slabs = [shard.slab(m, world, r) for r in range(world)]
+        assert slabs[0][0] == 0 and slabs[-1][1] == m
+        assert all(a[1] == b[0] for a, b in zip(slabs[:-1], slabs[1:]))
+        sizes = [b - a for a, b in slabs]
+        assert max(sizes) - min(sizes) <= 1
