@@ -257,6 +257,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_step(BigPsdView B, int arg) {
 constexpr int BJ_LD = BJ_W + 2;        // LDS leading dimension of the product operands (66: rows 2 banks apart)
 constexpr int BJ_ILD = BJ_W | 1;       // LDS leading dimension of the rotation sweep (65: row and column walks conflict free)
 constexpr int BJ_INNER_THREADS = 512;
+constexpr size_t BJ_INNER_LDS = (size_t)2 * BJ_W * BJ_ILD * sizeof(real) + BJ_B * (sizeof(RotCS) + sizeof(int2));
 constexpr size_t BJ_UPDATE_LDS = (size_t)4 * BJ_W * BJ_LD * sizeof(real);
 
 __device__ __forceinline__ int2 bj_pair(int i, int step, int nbc) { // round robin over block columns, as over columns
@@ -272,91 +273,18 @@ __device__ __forceinline__ int2 bj_pair(int i, int step, int nbc) { // round rob
 // global row / column of local index l (0..63) of the pair (I, J)
 __device__ __forceinline__ int bj_gidx(int2 IJ, int l) { return l < BJ_B ? IJ.x * BJ_B + l : IJ.y * BJ_B + (l - BJ_B); }
 
-// Qbuf / Sbuf: per (block, pair) 64 x 64 column-major; Qflag: 1 if the sweep rotated anything.
-// The sweep is software-pipelined over the workgroup's waves: wave 0 is the PARAMETER wave -- while waves 1..7 apply step
-// st (S_old -> S_new through a second LDS copy of S, Q in place), it forms the rotations of step st + 1 from S_old and the
-// current rotations (the three entries a pair needs, S'[p,q], S'[p,p], S'[q,q], are each one 2 x 2 block of S_old rotated
-// by two known rotations) -- so a step is ONE barrier and the fp64 sqrt / div / rsqrt chain of the parameters runs under
-// the update instead of in front of it (the two-barrier form of round 3's first version: 96 us per sweep).
-struct BjTables {
-  RotCS cs[BJ_B];
-  int2 pq[BJ_B];
-  int where[BJ_W]; // index -> 2 * pair + side (0: the pair's p, 1: its q)
-  int any;
-};
-constexpr size_t BJ_INNER_LDS = (size_t)3 * BJ_W * BJ_ILD * sizeof(real) + 2 * sizeof(BjTables);
-
-__device__ __forceinline__ int2 bj_local_pair(int i, int st) { // round robin over the 64 local indices
-  int p = i == 0 ? 0 : 1 + ((i - 1 + st) % (BJ_W - 1));
-  int q = 1 + ((BJ_W - 2 - i + st) % (BJ_W - 1));
-  if (p > q) {
-    const int t = p;
-    p = q;
-    q = t;
-  }
-  return make_int2(p, q);
-}
-// entry (a, b) of J' S J, J = the rotations of table T, from the unrotated S (same operation order as the block update)
-__device__ __forceinline__ real bj_rotated_entry(const real *S, const BjTables &T, int a, int b) {
-  const int wa = T.where[a], wb = T.where[b];
-  const int P = wa >> 1, Qi = wb >> 1, sa = wa & 1, sb = wb & 1;
-  const int2 pq1 = T.pq[P], pq2 = T.pq[Qi];
-  const RotCS r1 = T.cs[P], r2 = T.cs[Qi];
-  if (P == Qi && sa != sb && r1.s != (real)0) return (real)0; // a rotated pair's own entry
-  const real a11 = S[pq1.x * BJ_ILD + pq2.x], a12 = S[pq1.x * BJ_ILD + pq2.y];
-  const real a21 = S[pq1.y * BJ_ILD + pq2.x], a22 = S[pq1.y * BJ_ILD + pq2.y];
-  const real ra1 = sa == 0 ? r1.c * a11 - r1.s * a21 : r1.s * a11 + r1.c * a21;
-  const real ra2 = sa == 0 ? r1.c * a12 - r1.s * a22 : r1.s * a12 + r1.c * a22;
-  return sb == 0 ? r2.c * ra1 - r2.s * ra2 : r2.s * ra1 + r2.c * ra2;
-}
-// lanes 0..31 of ONE wave: rotations of step `st` into T.  `prev` (nullable): the rotations being applied to S right now
-__device__ __forceinline__ void bj_form_rotations(const real *S, const BjTables *prev, BjTables &T, int st, int lane, int2 IJ, int k,
-                                                  real thr, real &offmax) {
-  bool rot = false;
-  if (lane < BJ_B) {
-    const int2 pq = bj_local_pair(lane, st);
-    const int p = pq.x, q = pq.y;
-    real apq, app, aqq;
-    if (prev && prev->any) {
-      apq = bj_rotated_entry(S, *prev, p, q);
-      app = bj_rotated_entry(S, *prev, p, p);
-      aqq = bj_rotated_entry(S, *prev, q, q);
-    } else {
-      apq = S[p * BJ_ILD + q];
-      app = S[p * BJ_ILD + p];
-      aqq = S[q * BJ_ILD + q];
-    }
-    real c = 1, s = 0;
-    const real aa = absval(apq);
-    const bool real_pair = bj_gidx(IJ, q) < k; // local order = global order (I < J): q is the larger index
-    if (real_pair) offmax = aa > offmax ? aa : offmax;
-    if (real_pair && aa > thr) {
-      const real d = aqq - app, bb = (real)2 * apq;
-      const real h = sqrt(d * d + bb * bb);
-      const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
-      c = rsqrt(t * t + (real)1);
-      s = t * c;
-      rot = true;
-    }
-    T.pq[lane] = pq;
-    T.cs[lane] = RotCS{c, s};
-    T.where[p] = 2 * lane;
-    T.where[q] = 2 * lane + 1;
-  }
-  const int any = __any(rot) ? 1 : 0;
-  if (lane == 0) T.any = any;
-}
-
+// Qbuf / Sbuf: per (block, pair) 64 x 64 column-major; Qflag: 1 if the sweep rotated anything
 __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, real *Qbuf, real *Sbuf, int *Qflag, int npmax, int arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
-  real *Sb[2];
-  Sb[0] = reinterpret_cast<real *>(bj_smem);
-  Sb[1] = Sb[0] + BJ_W * BJ_ILD;
-  real *Q = Sb[1] + BJ_W * BJ_ILD;
-  BjTables *Tb = reinterpret_cast<BjTables *>(Q + BJ_W * BJ_ILD);
+  real *S = reinterpret_cast<real *>(bj_smem);
+  real *Q = S + BJ_W * BJ_ILD;
+  RotCS *rot_cs = reinterpret_cast<RotCS *>(Q + BJ_W * BJ_ILD);
+  int2 *rot_pq = reinterpret_cast<int2 *>(rot_cs + BJ_B);
   __shared__ real red[BJ_INNER_THREADS / SCSAMD_WAVE];
+  __shared__ volatile int rot_any[2];
+  __shared__ int rotated;
   const int slot = arg & 1, step = arg >> 1;
-  const int b = blockIdx.y, pi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.y, pi = blockIdx.x, tid = threadIdx.x;
   BigPsdCtl *ctl = B.ctl + b;
   const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
   const real thr = ctl->thr;
@@ -368,64 +296,79 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
   const int k = sh.k;
   for (int e = tid; e < BJ_W * BJ_W; e += BJ_INNER_THREADS) {
     const int r = e & (BJ_W - 1), c = e >> 6; // r fast: 32-entry runs of a column of A
-    Sb[0][r * BJ_ILD + c] = Aold[(size_t)bj_gidx(IJ, c) * ld + bj_gidx(IJ, r)];
+    S[r * BJ_ILD + c] = Aold[(size_t)bj_gidx(IJ, c) * ld + bj_gidx(IJ, r)];
     Q[r * BJ_ILD + c] = r == c ? (real)1 : (real)0;
   }
+  if (tid < 2) rot_any[tid] = 0;
+  if (tid == 0) rotated = 0;
   __syncthreads();
   real offmax = 0;
-  if (wave == 0) bj_form_rotations(Sb[0], nullptr, Tb[0], 0, lane, IJ, k, thr, offmax);
-  __syncthreads();
-  int sb = 0, rotated = 0; // which copy holds S; did any step rotate (uniform: everybody reads the same `any` words)
-  constexpr int NP = BJ_B, NUPD = BJ_INNER_THREADS - SCSAMD_WAVE; // 448 update lanes (waves 1..7)
+  constexpr int NP = BJ_B; // 32 pairs of the 64 local indices
   for (int st = 0; st < BJ_W - 1; ++st) {
-    const BjTables &T = Tb[st & 1];
-    const int any = T.any;
-    const real *So = Sb[sb];
-    if (wave == 0) {
-      // parameter wave: next step's rotations from S_old and the rotations being applied
-      if (st + 1 < BJ_W - 1) bj_form_rotations(So, &T, Tb[(st + 1) & 1], st + 1, lane, IJ, k, thr, offmax);
-    } else if (any) {
-      real *Sn = Sb[sb ^ 1];
-      for (int e = tid - SCSAMD_WAVE; e < NP * NP + BJ_W * NP; e += NUPD) {
-        if (e < NP * NP) {
-          const int Qi = e / NP, P = e % NP;
-          const int2 pq1 = T.pq[P], pq2 = T.pq[Qi];
-          const RotCS r1 = T.cs[P], r2 = T.cs[Qi];
-          const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
-          const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
-          const int i11 = p1 * BJ_ILD + p2, i12 = p1 * BJ_ILD + q2, i21 = q1 * BJ_ILD + p2, i22 = q1 * BJ_ILD + q2;
-          const real a11 = So[i11], a12 = So[i12], a21 = So[i21], a22 = So[i22];
-          const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
-          const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
-          const bool own = P == Qi && s1 != (real)0;
-          Sn[i11] = c2 * r11 - s2 * r12;
-          Sn[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
-          Sn[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
-          Sn[i22] = s2 * r21 + c2 * r22;
-        } else {
-          const int f = e - NP * NP, Qi = f / BJ_W, i = f % BJ_W;
-          const int2 pq2 = T.pq[Qi];
-          const RotCS r2 = T.cs[Qi];
-          const int ip = i * BJ_ILD + pq2.x, iq = i * BJ_ILD + pq2.y;
-          const real vp = Q[ip], vq = Q[iq];
-          Q[ip] = r2.c * vp - r2.s * vq;
-          Q[iq] = r2.s * vp + r2.c * vq;
-        }
+    const int par = st & 1;
+    if (tid < NP) {
+      const int i = tid;
+      int p = i == 0 ? 0 : 1 + ((i - 1 + st) % (BJ_W - 1));
+      int q = 1 + ((BJ_W - 2 - i + st) % (BJ_W - 1));
+      if (p > q) {
+        const int t = p;
+        p = q;
+        q = t;
       }
+      real c = 1, s = 0;
+      const real apq = S[p * BJ_ILD + q];
+      const real aa = absval(apq);
+      const bool real_pair = bj_gidx(IJ, q) < k; // local order = global order (I < J): q is the larger index
+      if (real_pair) offmax = aa > offmax ? aa : offmax;
+      if (real_pair && aa > thr) {
+        const real d = S[q * BJ_ILD + q] - S[p * BJ_ILD + p], bb = (real)2 * apq;
+        const real h = sqrt(d * d + bb * bb);
+        const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
+        c = rsqrt(t * t + (real)1);
+        s = t * c;
+        rot_any[par] = 1;
+      }
+      rot_pq[i] = make_int2(p, q);
+      rot_cs[i] = RotCS{c, s};
+      if (i == 0) rot_any[par ^ 1] = 0;
     }
-    if (any) {
-      sb ^= 1;
-      rotated = 1;
+    __syncthreads();
+    if (!rot_any[par]) continue; // uniform
+    if (tid == 0) rotated = 1;
+    for (int e = tid; e < NP * NP + BJ_W * NP; e += BJ_INNER_THREADS) {
+      if (e < NP * NP) {
+        const int Qi = e / NP, P = e % NP;
+        const int2 pq1 = rot_pq[P], pq2 = rot_pq[Qi];
+        const RotCS r1 = rot_cs[P], r2 = rot_cs[Qi];
+        const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
+        const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
+        const int i11 = p1 * BJ_ILD + p2, i12 = p1 * BJ_ILD + q2, i21 = q1 * BJ_ILD + p2, i22 = q1 * BJ_ILD + q2;
+        const real a11 = S[i11], a12 = S[i12], a21 = S[i21], a22 = S[i22];
+        const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
+        const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
+        const bool own = P == Qi && s1 != (real)0;
+        S[i11] = c2 * r11 - s2 * r12;
+        S[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
+        S[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
+        S[i22] = s2 * r21 + c2 * r22;
+      } else {
+        const int f = e - NP * NP, Qi = f / BJ_W, i = f % BJ_W;
+        const int2 pq2 = rot_pq[Qi];
+        const RotCS r2 = rot_cs[Qi];
+        const int ip = i * BJ_ILD + pq2.x, iq = i * BJ_ILD + pq2.y;
+        const real vp = Q[ip], vq = Q[iq];
+        Q[ip] = r2.c * vp - r2.s * vq;
+        Q[iq] = r2.s * vp + r2.c * vq;
+      }
     }
     __syncthreads();
   }
-  offmax = block_max(offmax, red);
+  offmax = block_max(offmax, red); // (contains the barriers that make `rotated` and the last pass visible)
   if (tid == 0) {
     if (offmax > (real)0) atomicMax(&ctl->offmax_bits, bp_bits(offmax));
     Qflag[(size_t)b * npmax + pi] = rotated;
   }
   if (!rotated) return; // uniform: nobody reads Q / S' of a pair whose flag is 0
-  const real *S = Sb[sb];
   real *Qg = Qbuf + ((size_t)b * npmax + pi) * BJ_W * BJ_W, *Sg = Sbuf + ((size_t)b * npmax + pi) * BJ_W * BJ_W;
   for (int e = tid; e < BJ_W * BJ_W; e += BJ_INNER_THREADS) {
     const int r = e & (BJ_W - 1), c = e >> 6;
