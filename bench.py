@@ -744,8 +744,9 @@ def main():
         if world == 1 and not stub and args.secondary == "all" and args.dtype == "f64":
             out["secondary"] = secondary_single_gpu(args)
         if want_cpu:
-            out["cpu_baseline"] = cpu_leg(args, n, 1, cpu1, args.cpu_baseline_timeout, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
+            # the OpenMP legs start while the 1-thread leg is still finishing (one extra core does not disturb them)
             out["cpu_baseline_omp"] = cpu_omp_sweep(args, n, cpu_early, gpu_win)
+            out["cpu_baseline"] = cpu_leg(args, n, 1, cpu1, args.cpu_baseline_timeout, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
         else:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())
