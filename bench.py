@@ -241,7 +241,7 @@ def cpu_omp_sweep(args, n, early, gpu_win):
         if thr in early or thr < 2 or any(l["cores"] == thr for l in legs):
             continue
         left = args.cpu_omp_budget - (time.time() - t_begin)
-        if left < 30:
+        if left < 50:  # a leg needs 30 - 60 s on this host (generation, scs_init, iteration 0, the window)
             legs.append(dict(value=None, cores=thr, sample="skipped: --cpu-omp-budget spent"))
             continue
         legs.append(cpu_leg(args, n, thr, _cpu_start(cpu_spec(args, n, thr)), min(left, args.cpu_baseline_timeout), gpu_win))
