@@ -138,6 +138,7 @@ struct WaveRowsDev {
   int pipelined = 0;           // 1: one chunk of stream in flight ahead of the gathers (csr_wave_kernel<.., 1>): matrices whose gathers share lines
   double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
+  int wpc = 8;                 // waves per CU the layout is cut for (one unit per resident wave); SCS_AMD_WR_WPC overrides (measurements)
   DevBuf<int> urow, useg;
   DevBuf<unsigned> wrd;
   DevBuf<real> val;
@@ -148,7 +149,7 @@ struct WaveRowsDev {
   // (measured at n = 4e6: 415 us per product with 1954 workgroups vs the resident grid)
   // equal rounds: with R = ceil(nunit / (8 cus)) rounds, ceil(nunit / R) units run at a time
   int grid() const {
-    const int resident = 8 * cus;
+    const int resident = wpc * cus;
     const int rounds = std::max(1, (nunit + resident - 1) / resident);
     const int per_round = (nunit + rounds - 1) / rounds;
     return std::max(1, std::min((per_round + WR_WPB - 1) / WR_WPB, WR_MAX_GRID));
@@ -179,7 +180,8 @@ struct WaveRowsDev {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
       cus = 256;
-    long long budget = std::max<long long>(1024, (nnz_all + 8LL * cus - 1) / (8LL * cus));
+    if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
+    long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
     if (const char *e = getenv("SCS_AMD_WR_NNZ")) budget = std::max(64, atoi(e));
     std::vector<int> ur, us;
     auto partition = [&](long long bud) {
@@ -203,7 +205,7 @@ struct WaveRowsDev {
     // (measured: 513 workgroups on 512 slots 86 us vs 71 us): widen the budget until the units fit, unless
     // the row cap (packed word) is what limits them
     if (!getenv("SCS_AMD_WR_NNZ"))
-      for (int tries = 0; (long long)ur.size() - 1 > 8LL * cus && (long long)rows <= (long long)rows_cap * 8 * cus && tries < 60; ++tries) {
+      for (int tries = 0; (long long)ur.size() - 1 > (long long)wpc * cus && (long long)rows <= (long long)rows_cap * wpc * cus && tries < 60; ++tries) {
         budget += std::max<long long>(1, budget / 100);
         partition(budget);
       }
