@@ -59,3 +59,30 @@ def test_one_rank_under_torchrun_runs_its_collectives_over_rccl():
     assert abs(rccl["value"] - plain["value"]) <= 0.03 * plain["value"], (rccl["value"], plain["value"])
     assert len(rccl["per_rank_it_per_s"]) == 1 and rccl["per_rank_it_per_s"][0] > 0
     assert rccl["batch"]["problems"] == 2 and rccl["batch"]["all_solved"]
+
+
+def test_side_workloads_of_the_default_line_at_reduced_sizes():
+    """The `secondary` block of the default bench line (configs[2] SDP, configs[4] fp32 carried to eps with fp64 host
+    residuals, the locality variants) and the OpenMP-sweep plumbing, at sizes that take seconds: every field the driver's
+    line carries must be there and sane."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "60000", "--fp32-n", "120000", "--steps", "10", "--warmup", "5",
+                          "--batch-n", "8000", "--batch-per-gpu", "2", "--batch-concurrency", "2", "--cpu-omp-sweep", "4", "--cpu-omp-budget", "120",
+                          "--cpu-window-iters", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["status"] == "solved" and d["roofline"]["bound"] == "hbm" and "parity_mode" in d
+    s = d["secondary"]
+    assert s["configs2_sdp"]["status"] == "solved" and s["configs2_sdp"]["ms_per_projection"] > 0
+    f32 = s["configs4_fp32"]
+    assert f32["status"] == "solved" and f32["iters_to_eps"] > 0 and f32["final_fp64_host_recomputed"]["meets_eps"] is True
+    for band in ("band_1024", "band_4096"):
+        assert s["locality_variant"][band]["window_it_per_s"] > 0
+    assert d["batch"]["all_solved"]
+    from oracle import pyoracle
+    if pyoracle.ref_available():
+        assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+        legs = d["cpu_baseline_omp"]["legs"]
+        assert legs and legs[0]["cores"] == 4 and legs[0]["value"] > 0
