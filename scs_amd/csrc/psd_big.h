@@ -256,8 +256,14 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_step(BigPsdView B, int arg) {
 // multiple of 64) are zero in A and unit in V; a rotation never touches them (q < k, as in the LDS kernel).
 constexpr int BJ_LD = BJ_W + 2;        // LDS leading dimension of the product operands (66: rows 2 banks apart)
 constexpr int BJ_ILD = BJ_W | 1;       // LDS leading dimension of the rotation sweep (65: row and column walks conflict free)
+#ifndef BJ_INNER_THREADS_OVERRIDE
 constexpr int BJ_INNER_THREADS = 512;
-static_assert(BJ_B * BJ_B == 2 * BJ_INNER_THREADS && BJ_W * BJ_B == 4 * BJ_INNER_THREADS, "k_bj_inner: two 2x2 blocks and four row pairs per lane");
+#else
+constexpr int BJ_INNER_THREADS = BJ_INNER_THREADS_OVERRIDE;
+#endif
+constexpr int BJ_NBLK = BJ_B * BJ_B / BJ_INNER_THREADS; // 2x2 blocks of S per lane and inner step
+constexpr int BJ_NROW = BJ_W * BJ_B / BJ_INNER_THREADS; // row pairs of Q per lane and inner step
+static_assert(BJ_NBLK * BJ_INNER_THREADS == BJ_B * BJ_B && BJ_NROW * BJ_INNER_THREADS == BJ_W * BJ_B, "k_bj_inner: whole items per lane");
 constexpr size_t BJ_INNER_LDS = (size_t)2 * BJ_W * BJ_ILD * sizeof(real) + BJ_B * (sizeof(RotCS) + sizeof(int2));
 constexpr size_t BJ_UPDATE_LDS = (size_t)4 * BJ_W * BJ_LD * sizeof(real);
 
@@ -336,15 +342,15 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
     __syncthreads();
     if (!rot_any[par]) continue; // uniform
     if (tid == 0) rotated = 1;
-    // 1024 2x2 blocks of S and 2048 row pairs of Q over 512 lanes: every lane owns two blocks and four row pairs, and asks
+    // 1024 2x2 blocks of S and 2048 row pairs of Q over the lanes: every lane owns BJ_NBLK blocks and BJ_NROW row pairs, and asks
     // for all its tables, then all its operands, before it computes -- the LDS round trips of the six items overlap
     // instead of queueing behind each other (an item loop measured 96 us per sweep: six dependent round trips per step)
     {
-      int i11[2], i12[2], i21[2], i22[2];
-      RotCS r1[2], r2[2];
-      bool own[2];
+      int i11[BJ_NBLK], i12[BJ_NBLK], i21[BJ_NBLK], i22[BJ_NBLK];
+      RotCS r1[BJ_NBLK], r2[BJ_NBLK];
+      bool own[BJ_NBLK];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < BJ_NBLK; ++u) {
         const int e = tid + u * BJ_INNER_THREADS, Qi = e / NP, P = e % NP;
         const int2 pq1 = rot_pq[P], pq2 = rot_pq[Qi];
         r1[u] = rot_cs[P];
@@ -355,31 +361,31 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
         i22[u] = pq1.y * BJ_ILD + pq2.y;
         own[u] = P == Qi && r1[u].s != (real)0;
       }
-      int ip[4], iq[4];
-      RotCS rq[4];
+      int ip[BJ_NROW], iq[BJ_NROW];
+      RotCS rq[BJ_NROW];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < BJ_NROW; ++j) {
         const int f = tid + j * BJ_INNER_THREADS, Qi = f / BJ_W, i = f % BJ_W;
         const int2 pq2 = rot_pq[Qi];
         rq[j] = rot_cs[Qi];
         ip[j] = i * BJ_ILD + pq2.x;
         iq[j] = i * BJ_ILD + pq2.y;
       }
-      real a11[2], a12[2], a21[2], a22[2], vp[4], vq[4];
+      real a11[BJ_NBLK], a12[BJ_NBLK], a21[BJ_NBLK], a22[BJ_NBLK], vp[BJ_NROW], vq[BJ_NROW];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < BJ_NBLK; ++u) {
         a11[u] = S[i11[u]];
         a12[u] = S[i12[u]];
         a21[u] = S[i21[u]];
         a22[u] = S[i22[u]];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < BJ_NROW; ++j) {
         vp[j] = Q[ip[j]];
         vq[j] = Q[iq[j]];
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < BJ_NBLK; ++u) {
         const real c1 = r1[u].c, s1 = r1[u].s, c2 = r2[u].c, s2 = r2[u].s;
         const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
         const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
         S[i22[u]] = s2 * r21 + c2 * r22;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < BJ_NROW; ++j) {
         Q[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
         Q[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
       }
