@@ -528,73 +528,35 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q);
         // V <- V J over (row, pair) items.  One barrier per step for both.
         const int nblk = npairs * npairs, nv = K2 * npairs;
-        // four items per lane and pass, tables first, then every operand, then the arithmetic: the LDS round trips of a lane's
-        // items overlap instead of queueing behind each other (one item at a time: 0.28 ms per projection of configs[2];
-        // same arithmetic, same results)
-        constexpr int PU = 4;
-        for (int base = tid; base < nblk + nv; base += PU * PSD_THREADS) {
-          int ia[PU], ib[PU], ic[PU], id[PU]; // block: (p1,p2) (p1,q2) (q1,p2) (q1,q2); row pair of V: ia, ib only
-          RotCS ra[PU], rb[PU];
-          int kind[PU]; // 0 nothing, 1 block, 2 block holding a rotated pair's own entries, 3 row pair of V
-#pragma unroll
-          for (int u = 0; u < PU; ++u) {
-            const int e = base + u * PSD_THREADS;
-            kind[u] = 0;
-            ia[u] = ib[u] = ic[u] = id[u] = 0;
-            ra[u] = rb[u] = RotCS{(real)1, (real)0};
-            if (e < nblk) {
-              // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> distinct LDS banks); the column pair is
-              // uniform across most of a wave
-              const int Q = e / npairs, P = e % npairs;
-              const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
-              ra[u] = rot_cs[P];
-              rb[u] = rot_cs[Q];
-              ia[u] = MI(pq1.x, pq2.x);
-              ib[u] = MI(pq1.x, pq2.y);
-              ic[u] = MI(pq1.y, pq2.x);
-              id[u] = MI(pq1.y, pq2.y);
-              kind[u] = (P == Q && ra[u].s != (real)0) ? 2 : 1;
-            } else if (e < nblk + nv) {
-              const int f = e - nblk, Q = f / K2, i = f % K2; // consecutive rows: stride ld
-              const int2 pq2 = rot_pq[Q];
-              rb[u] = rot_cs[Q];
-              ia[u] = MI(i, pq2.x);
-              ib[u] = MI(i, pq2.y);
-              kind[u] = 3;
-            }
-          }
-          real va[PU], vb[PU], vc[PU], vd[PU];
-#pragma unroll
-          for (int u = 0; u < PU; ++u) {
-            va[u] = vb[u] = vc[u] = vd[u] = 0;
-            if (kind[u] == 3) {
-              va[u] = V[ia[u]];
-              vb[u] = V[ib[u]];
-            } else if (kind[u]) {
-              va[u] = A[ia[u]];
-              vb[u] = A[ib[u]];
-              vc[u] = A[ic[u]];
-              vd[u] = A[id[u]];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < PU; ++u) {
-            if (kind[u] == 3) {
-              V[ia[u]] = rb[u].c * va[u] - rb[u].s * vb[u];
-              V[ib[u]] = rb[u].s * va[u] + rb[u].c * vb[u];
-            } else if (kind[u]) {
-              const real c1 = ra[u].c, s1 = ra[u].s, c2 = rb[u].c, s2 = rb[u].s;
-              const real r11 = c1 * va[u] - s1 * vc[u], r12 = c1 * vb[u] - s1 * vd[u];
-              const real r21 = s1 * va[u] + c1 * vc[u], r22 = s1 * vb[u] + c1 * vd[u];
-              // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is
-              // left otherwise is rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the
-              // convergence threshold and kept the sweeps going to the cap)
-              const bool own = kind[u] == 2;
-              A[ia[u]] = c2 * r11 - s2 * r12;
-              A[ib[u]] = own ? (real)0 : s2 * r11 + c2 * r12;
-              A[ic[u]] = own ? (real)0 : c2 * r21 - s2 * r22;
-              A[id[u]] = s2 * r21 + c2 * r22;
-            }
+        for (int e = tid; e < nblk + nv; e += PSD_THREADS) {
+          if (e < nblk) {
+            // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> conflict-free LDS
+            // banks); the column pair is uniform across most of a wave
+            const int Q = e / npairs, P = e % npairs;
+            const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
+            const RotCS r1 = rot_cs[P], r2 = rot_cs[Q];
+            const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
+            const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
+            const int i11 = MI(p1, p2), i12 = MI(p1, q2), i21 = MI(q1, p2), i22 = MI(q1, q2);
+            const real a11 = A[i11], a12 = A[i12], a21 = A[i21], a22 = A[i22];
+            const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
+            const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
+            // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is
+            // left otherwise is rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the
+            // convergence threshold and kept the sweeps going to the cap)
+            const bool own = P == Q && s1 != (real)0;
+            A[i11] = c2 * r11 - s2 * r12;
+            A[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
+            A[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
+            A[i22] = s2 * r21 + c2 * r22;
+          } else {
+            const int f = e - nblk, Q = f / K2, i = f % K2; // consecutive rows: stride ld
+            const int2 pq2 = rot_pq[Q];
+            const RotCS r2 = rot_cs[Q];
+            const int ip = MI(i, pq2.x), iq = MI(i, pq2.y);
+            const real vp = V[ip], vq = V[iq];
+            V[ip] = r2.c * vp - r2.s * vq;
+            V[iq] = r2.s * vp + r2.c * vq;
           }
         }
         __syncthreads();
