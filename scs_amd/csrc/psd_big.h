@@ -416,13 +416,18 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
   }
 }
 
+#ifndef BJ_UPD_THREADS_OVERRIDE
+constexpr int BJ_UPD_THREADS = 512; // eight waves: two 16 x 16 output tiles each per product, 8 tile elements per lane and copy loop
+#else
+constexpr int BJ_UPD_THREADS = BJ_UPD_THREADS_OVERRIDE;
+#endif
 // O[i][j] = sum_k L[i][k] R[k][j] for 64 x 64 operands in LDS: L[i][k] at L[i * BJ_LD + k], R[k][j] at R[j * BJ_LD + k] (both
-// contiguous along the summation index), O[i][j] at O[j * BJ_LD + i].  Four waves, four 16 x 16 tiles each; lane
+// contiguous along the summation index), O[i][j] at O[j * BJ_LD + i].  16 x 16 output tiles dealt to the waves; lane
 // (li = l & 15, lk = l >> 4) supplies L[16 ti + li][4 ks + lk] and R[4 ks + lk][16 tj + li].
 __device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O, int tid) {
 #ifndef SFLOAT
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  for (int t = wave; t < 16; t += BP_THREADS / SCSAMD_WAVE) {
+  for (int t = wave; t < 16; t += BJ_UPD_THREADS / SCSAMD_WAVE) {
     const int ti = t & 3, tj = t >> 2;
     const real *lp = L + (ti * 16 + li) * BJ_LD + lk, *rp = R + (tj * 16 + li) * BJ_LD + lk;
     f64x4 acc = {0, 0, 0, 0};
@@ -432,7 +437,7 @@ __device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O,
     for (int r = 0; r < 4; ++r) O[(tj * 16 + li) * BJ_LD + ti * 16 + lk + 4 * r] = acc[r];
   }
 #else
-  for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+  for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
     const int i = e & (BJ_W - 1), j = e >> 6;
     real acc = 0;
     for (int kk = 0; kk < BJ_W; ++kk) acc += L[i * BJ_LD + kk] * R[j * BJ_LD + kk];
@@ -441,7 +446,7 @@ __device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O,
 #endif
 }
 
-__global__ __launch_bounds__(BP_THREADS) void k_bj_update(BigPsdView B, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
+__global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
                                                           const int *__restrict__ Qflag, int npmax, int arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
   real *xs = reinterpret_cast<real *>(bj_smem);
@@ -468,14 +473,14 @@ __global__ __launch_bounds__(BP_THREADS) void k_bj_update(BigPsdView B, const re
     const int2 IJp = bj_pair(Pp, step, sh.nbc), IJq = bj_pair(Qp, step, sh.nbc);
     const int fP = flags[Pp], fQ = flags[Qp];
     if (Pp == Qp && fP) { // the pair's own tile: the inner sweep's S' (exact zeros, relatively accurate small entries)
-      for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+      for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
         const int i = e & (BJ_W - 1), j = e >> 6;
         Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = Sb[(size_t)Pp * BJ_W * BJ_W + j * BJ_W + i];
       }
       return;
     }
     if (!fP && !fQ) { // neither pair rotated: the tile moves to the other copy as it is
-      for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+      for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
         const int i = e & (BJ_W - 1), j = e >> 6;
         const size_t g = (size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i);
         Anew[g] = Aold[g];
@@ -483,7 +488,8 @@ __global__ __launch_bounds__(BP_THREADS) void k_bj_update(BigPsdView B, const re
       return;
     }
     // X[i][k] = A[P_i, Q_k]; Q_Q[k][j] and Q_P[k][i], identity where the pair did not rotate
-    for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+#pragma unroll 4
+    for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
       const int i = e & (BJ_W - 1), kk = e >> 6;
       xs[i * BJ_LD + kk] = Aold[(size_t)bj_gidx(IJq, kk) * ld + bj_gidx(IJp, i)];
       // Qbuf is column-major: Q[k][j] at j * 64 + k -> qq[j * BJ_LD + k]: here (kk, i) play (j, k)
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_bj_update(BigPsdView B, const re
     __syncthreads();
     bj_gemm64(qp, ts, xs, tid); // O = Q_P' T: L[i][k] = Q_P[k][i] = qp[i * BJ_LD + k], R[k][j] = T[k][j] = ts[j * BJ_LD + k]
     __syncthreads();
-    for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+    for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
       const int i = e & (BJ_W - 1), j = e >> 6;
       Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = xs[j * BJ_LD + i];
     }
@@ -506,7 +512,8 @@ __global__ __launch_bounds__(BP_THREADS) void k_bj_update(BigPsdView B, const re
   const int Qp = tile / TR, r0 = (tile % TR) * BJ_W;
   if (!flags[Qp]) return;
   const int2 IJq = bj_pair(Qp, step, sh.nbc);
-  for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+#pragma unroll 4
+  for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
     const int i = e & (BJ_W - 1), kk = e >> 6;
     xs[i * BJ_LD + kk] = V[(size_t)bj_gidx(IJq, kk) * ld + r0 + i];
     qq[kk * BJ_LD + i] = Qb[(size_t)Qp * BJ_W * BJ_W + kk * BJ_W + i];
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_bj_update(BigPsdView B, const re
   __syncthreads();
   bj_gemm64(xs, qq, ts, tid);
   __syncthreads();
-  for (int e = tid; e < BJ_W * BJ_W; e += BP_THREADS) {
+  for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
     const int i = e & (BJ_W - 1), j = e >> 6;
     V[(size_t)bj_gidx(IJq, j) * ld + r0 + i] = ts[j * BJ_LD + i];
   }
@@ -792,7 +799,7 @@ struct BigPsd {
         for (int step = 0; step < nbc_max - 1; ++step, ++gstep) {
           const int arg = (int)(gstep & 1) | (step << 1);
           hipLaunchKernelGGL(k_bj_inner, dim3(npmax, nbig), dim3(BJ_INNER_THREADS), BJ_INNER_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, arg);
-          hipLaunchKernelGGL(k_bj_update, dim3(g_upd, nbig), dim3(BP_THREADS), BJ_UPDATE_LDS, st, B, (const real *)Qbuf.p,
+          hipLaunchKernelGGL(k_bj_update, dim3(g_upd, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, (const real *)Qbuf.p,
                              (const real *)Sbuf.p, (const int *)Qflag.p, npmax, arg);
         }
       } else {
