@@ -277,11 +277,44 @@ __device__ __forceinline__ int2 bj_pair(int i, int step, int nbc) { // round rob
   }
   return make_int2(I, J);
 }
+// The sweep's schedule (SCS_AMD_PSD_CROSS, default on): outer step 0 pairs the block columns (0,1), (2,3), ... and rotates only WITHIN
+// each block column (two independent round robins over 32 indices, 31 inner steps); outer steps 1 .. nbc - 1 are the tournament over
+// block columns and rotate only the CROSS pairs (p in I, q in J; 32 inner steps of the cyclic shift q = (i + st) mod 32): every index
+// pair is rotated exactly once per sweep -- a cyclic Jacobi ordering -- instead of the within-block pairs once per outer step.
+// The numpy emulation of this schedule needs 10 - 12 sweeps where the full 63-step subproblem sweep needs 8 - 10; an outer step costs
+// half.  ostep = the `step` field of a launch: 0 = the within pass, s >= 1 = tournament step s - 1 (cross schedule); with the full
+// schedule ostep = tournament step, no within pass.
+__device__ __forceinline__ int2 bj_pair_sched(int i, int ostep, int nbc, int cross) {
+  if (!cross) return bj_pair(i, ostep, nbc);
+  if (ostep == 0) return make_int2(2 * i, 2 * i + 1);
+  return bj_pair(i, ostep - 1, nbc);
+}
+__device__ __forceinline__ int bj_outer_steps(int nbc, int cross) { return cross ? nbc : nbc - 1; }
+// pair i (0..31) of inner step st for the three kinds of inner sweep
+__device__ __forceinline__ int2 bj_inner_pair(int i, int st, int kind) { // kind 0: full round robin over 64; 1: within; 2: cross
+  int p, q;
+  if (kind == 2) {
+    p = i;
+    q = BJ_B + ((i + st) & (BJ_B - 1));
+  } else {
+    const int n = kind == 1 ? BJ_B : BJ_W, j = kind == 1 ? (i & (BJ_B / 2 - 1)) : i, off = kind == 1 && i >= BJ_B / 2 ? BJ_B : 0;
+    p = j == 0 ? 0 : 1 + ((j - 1 + st) % (n - 1));
+    q = 1 + ((n - 2 - j + st) % (n - 1));
+    if (p > q) {
+      const int t = p;
+      p = q;
+      q = t;
+    }
+    p += off;
+    q += off;
+  }
+  return make_int2(p, q);
+}
 // global row / column of local index l (0..63) of the pair (I, J)
 __device__ __forceinline__ int bj_gidx(int2 IJ, int l) { return l < BJ_B ? IJ.x * BJ_B + l : IJ.y * BJ_B + (l - BJ_B); }
 
 // Qbuf / Sbuf: per (block, pair) 64 x 64 column-major; Qflag: 1 if the sweep rotated anything
-__global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, real *Qbuf, real *Sbuf, int *Qflag, int npmax, int arg) {
+__global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, real *Qbuf, real *Sbuf, int *Qflag, int npmax, int arg, int cross) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
   real *S = reinterpret_cast<real *>(bj_smem);
   real *Q = S + BJ_W * BJ_ILD;
@@ -296,8 +329,10 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
   const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
   const real thr = ctl->thr;
   const BlockShape sh = bp_shape_raw(kraw);
-  if (done || step >= sh.nbc - 1 || pi >= sh.nbc / 2) return;
-  const int2 IJ = bj_pair(pi, step, sh.nbc);
+  if (done || step >= bj_outer_steps(sh.nbc, cross) || pi >= sh.nbc / 2) return;
+  const int2 IJ = bj_pair_sched(pi, step, sh.nbc, cross);
+  const int kind = !cross ? 0 : (step == 0 ? 1 : 2);
+  const int nst = kind == 0 ? BJ_W - 1 : (kind == 1 ? BJ_B - 1 : BJ_B);
   const size_t ld = B.ld, mat = (size_t)b * ld * ld;
   const real *Aold = (cur ? B.A1 : B.A) + mat;
   const int k = sh.k;
@@ -311,17 +346,12 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
   __syncthreads();
   real offmax = 0;
   constexpr int NP = BJ_B; // 32 pairs of the 64 local indices
-  for (int st = 0; st < BJ_W - 1; ++st) {
+  for (int st = 0; st < nst; ++st) {
     const int par = st & 1;
     if (tid < NP) {
       const int i = tid;
-      int p = i == 0 ? 0 : 1 + ((i - 1 + st) % (BJ_W - 1));
-      int q = 1 + ((BJ_W - 2 - i + st) % (BJ_W - 1));
-      if (p > q) {
-        const int t = p;
-        p = q;
-        q = t;
-      }
+      const int2 pq_i = bj_inner_pair(i, st, kind);
+      const int p = pq_i.x, q = pq_i.y;
       real c = 1, s = 0;
       const real apq = S[p * BJ_ILD + q];
       const real aa = absval(apq);
@@ -447,7 +477,7 @@ __device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O,
 }
 
 __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
-                                                          const int *__restrict__ Qflag, int npmax, int arg) {
+                                                          const int *__restrict__ Qflag, int npmax, int arg, int cross) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
   real *xs = reinterpret_cast<real *>(bj_smem);
   real *qp = xs + BJ_W * BJ_LD, *qq = qp + BJ_W * BJ_LD, *ts = qq + BJ_W * BJ_LD;
@@ -456,7 +486,7 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
   BigPsdCtl *ctl = B.ctl + b;
   const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
   const BlockShape sh = bp_shape_raw(kraw);
-  const bool active = !done && step < sh.nbc - 1;
+  const bool active = !done && step < bj_outer_steps(sh.nbc, cross);
   if (blockIdx.x == 0 && tid == 0) ctl->cur[slot ^ 1] = active ? cur ^ 1 : cur;
   if (!active) return;
   const size_t ld = B.ld, mat = (size_t)b * ld * ld;
@@ -470,7 +500,7 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
   const real *Qb = Qbuf + (size_t)b * npmax * BJ_W * BJ_W, *Sb = Sbuf + (size_t)b * npmax * BJ_W * BJ_W;
   if (tile < nta) {
     const int Pp = tile % np, Qp = tile / np;
-    const int2 IJp = bj_pair(Pp, step, sh.nbc), IJq = bj_pair(Qp, step, sh.nbc);
+    const int2 IJp = bj_pair_sched(Pp, step, sh.nbc, cross), IJq = bj_pair_sched(Qp, step, sh.nbc, cross);
     const int fP = flags[Pp], fQ = flags[Qp];
     if (Pp == Qp && fP) { // the pair's own tile: the inner sweep's S' (exact zeros, relatively accurate small entries)
       for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
@@ -511,7 +541,7 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
   tile -= nta;
   const int Qp = tile / TR, r0 = (tile % TR) * BJ_W;
   if (!flags[Qp]) return;
-  const int2 IJq = bj_pair(Qp, step, sh.nbc);
+  const int2 IJq = bj_pair_sched(Qp, step, sh.nbc, cross);
 #pragma unroll 4
   for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
     const int i = e & (BJ_W - 1), kk = e >> 6;
@@ -723,6 +753,7 @@ struct BigPsd {
   long long sweeps_total = 0, projections = 0;
   bool warm_ok = true;
   bool blocked = true;       // tournament over 32-wide block columns with MFMA updates (k_bj_*); false: single columns (k_bp_step)
+  bool cross = true;         // blocked: every index pair once per sweep (within pass + cross-pair tournament steps), see bj_pair_sched
   DevBuf<real> Qbuf, Sbuf;   // blocked: per (block, block-column pair) the 64 x 64 factor Q and rotated subproblem S'
   DevBuf<int> Qflag;         // ... and whether the pair's inner sweep rotated at all
   void reset_warm_start() { calls = 0; have_basis = false; }
@@ -743,6 +774,8 @@ struct BigPsd {
     blocked = true;
     if (const char *e = getenv("SCS_AMD_PSD_BLOCKED")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
     ld = blocked ? (kmax + BJ_W - 1) / BJ_W * BJ_W : (kmax + 1) & ~1;
+    cross = true;
+    if (const char *e = getenv("SCS_AMD_PSD_CROSS")) cross = atoi(e) != 0; // 0: full 63-step sweeps of every block-column pair (first form of round 3)
     if (blocked) {
       const size_t npmax = (size_t)ld / BJ_W;
       Qbuf.alloc((size_t)nbig * npmax * BJ_W * BJ_W);
@@ -796,11 +829,13 @@ struct BigPsd {
     const int g_upd = npmax * npmax + npmax * (ld / BJ_W); // A tiles + V tiles of the largest block
     for (int sweep = 0; sweep < PSD_MAX_SWEEPS && h_rem > 0; ++sweep) {
       if (blocked) {
-        for (int step = 0; step < nbc_max - 1; ++step, ++gstep) {
+        const int osteps = cross ? nbc_max : nbc_max - 1; // cross schedule: the within pass, then the tournament steps
+        for (int step = 0; step < osteps; ++step, ++gstep) {
           const int arg = (int)(gstep & 1) | (step << 1);
-          hipLaunchKernelGGL(k_bj_inner, dim3(npmax, nbig), dim3(BJ_INNER_THREADS), BJ_INNER_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, arg);
+          hipLaunchKernelGGL(k_bj_inner, dim3(npmax, nbig), dim3(BJ_INNER_THREADS), BJ_INNER_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, arg,
+                             cross ? 1 : 0);
           hipLaunchKernelGGL(k_bj_update, dim3(g_upd, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, (const real *)Qbuf.p,
-                             (const real *)Sbuf.p, (const int *)Qflag.p, npmax, arg);
+                             (const real *)Sbuf.p, (const int *)Qflag.p, npmax, arg, cross ? 1 : 0);
         }
       } else {
         for (int step = 0; step < ld - 1; ++step, ++gstep)
