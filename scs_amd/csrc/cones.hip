@@ -396,6 +396,87 @@ __device__ __forceinline__ real psd_unpack_entry(const real *X, int k, bool cplx
   return v;
 }
 
+// One update pass of the LDS Jacobi kernel, A <- J' A J over 2x2 blocks (rows of pair P, columns of pair Q) and V <- V J over
+// (row, pair) items (there are exactly twice as many of those): every lane owns up to NB blocks and 2 NB row pairs and asks for all
+// its tables, then all its operands, before it computes -- the LDS round trips of a lane's items overlap instead of queueing behind
+// each other.  Items beyond the end are clamped to item 0 for the loads and skipped by the stores (no per-item branches in the
+// load phase).  Same arithmetic as the one-item-at-a-time loop it replaces.
+template <int NB>
+__device__ __forceinline__ void psd_update_pass(real *A, real *V, const int2 *rot_pq, const RotCS *rot_cs, int npairs, int K2, int ld,
+                                                int tid) {
+  constexpr int NV = 2 * NB;
+  const int nblk = npairs * npairs, nv = 2 * nblk; // K2 * npairs == 2 * npairs^2
+  int i11[NB], i12[NB], i21[NB], i22[NB];
+  RotCS r1[NB], r2[NB];
+  bool okb[NB], own[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int e = tid + u * PSD_THREADS;
+    okb[u] = e < nblk;
+    const int ec = okb[u] ? e : 0;
+    // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> distinct LDS banks); the column pair is uniform across
+    // most of a wave
+    const int Q = ec / npairs, P = ec % npairs;
+    const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
+    r1[u] = rot_cs[P];
+    r2[u] = rot_cs[Q];
+    i11[u] = pq1.x * ld + pq2.x;
+    i12[u] = pq1.x * ld + pq2.y;
+    i21[u] = pq1.y * ld + pq2.x;
+    i22[u] = pq1.y * ld + pq2.y;
+    // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is left otherwise is
+    // rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the convergence threshold and kept
+    // the sweeps going to the cap)
+    own[u] = P == Q && r1[u].s != (real)0;
+  }
+  int ip[NV], iq[NV];
+  RotCS rq[NV];
+  bool okv[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int f = tid + j * PSD_THREADS;
+    okv[j] = f < nv;
+    const int fc = okv[j] ? f : 0;
+    const int Q = fc / K2, i = fc % K2; // consecutive rows: stride ld
+    const int2 pq2 = rot_pq[Q];
+    rq[j] = rot_cs[Q];
+    ip[j] = i * ld + pq2.x;
+    iq[j] = i * ld + pq2.y;
+  }
+  real a11[NB], a12[NB], a21[NB], a22[NB], vp[NV], vq[NV];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    a11[u] = A[i11[u]];
+    a12[u] = A[i12[u]];
+    a21[u] = A[i21[u]];
+    a22[u] = A[i22[u]];
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    vp[j] = V[ip[j]];
+    vq[j] = V[iq[j]];
+  }
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    if (okb[u]) {
+      const real c1 = r1[u].c, s1 = r1[u].s, c2 = r2[u].c, s2 = r2[u].s;
+      const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
+      const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
+      A[i11[u]] = c2 * r11 - s2 * r12;
+      A[i12[u]] = own[u] ? (real)0 : s2 * r11 + c2 * r12;
+      A[i21[u]] = own[u] ? (real)0 : c2 * r21 - s2 * r22;
+      A[i22[u]] = s2 * r21 + c2 * r22;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (okv[j]) {
+      V[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
+      V[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
+    }
+  }
+}
+
 // vprev (nullable): per cone a K2m x ldm eigenbasis carried from the previous projection.  With
 // warm != 0 the iteration starts from A' = Vp' A Vp (nearly diagonal when consecutive ADMM
 // iterates are close) and V = Vp, so it needs 1-2 sweeps instead of ~8; the basis is written back
@@ -527,37 +608,12 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         if (!rot_any[par]) continue; // uniform: every pair of this step is already converged
         // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q);
         // V <- V J over (row, pair) items.  One barrier per step for both.
-        const int nblk = npairs * npairs, nv = K2 * npairs;
-        for (int e = tid; e < nblk + nv; e += PSD_THREADS) {
-          if (e < nblk) {
-            // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> conflict-free LDS
-            // banks); the column pair is uniform across most of a wave
-            const int Q = e / npairs, P = e % npairs;
-            const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
-            const RotCS r1 = rot_cs[P], r2 = rot_cs[Q];
-            const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
-            const real c1 = r1.c, s1 = r1.s, c2 = r2.c, s2 = r2.s;
-            const int i11 = MI(p1, p2), i12 = MI(p1, q2), i21 = MI(q1, p2), i22 = MI(q1, q2);
-            const real a11 = A[i11], a12 = A[i12], a21 = A[i21], a22 = A[i22];
-            const real r11 = c1 * a11 - s1 * a21, r12 = c1 * a12 - s1 * a22;
-            const real r21 = s1 * a11 + c1 * a21, r22 = s1 * a12 + c1 * a22;
-            // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is
-            // left otherwise is rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the
-            // convergence threshold and kept the sweeps going to the cap)
-            const bool own = P == Q && s1 != (real)0;
-            A[i11] = c2 * r11 - s2 * r12;
-            A[i12] = own ? (real)0 : s2 * r11 + c2 * r12;
-            A[i21] = own ? (real)0 : c2 * r21 - s2 * r22;
-            A[i22] = s2 * r21 + c2 * r22;
-          } else {
-            const int f = e - nblk, Q = f / K2, i = f % K2; // consecutive rows: stride ld
-            const int2 pq2 = rot_pq[Q];
-            const RotCS r2 = rot_cs[Q];
-            const int ip = MI(i, pq2.x), iq = MI(i, pq2.y);
-            const real vp = V[ip], vq = V[iq];
-            V[ip] = r2.c * vp - r2.s * vq;
-            V[iq] = r2.s * vp + r2.c * vq;
-          }
+        switch ((npairs * npairs + PSD_THREADS - 1) / PSD_THREADS) { // blocks per lane (uniform over the workgroup)
+        case 1: psd_update_pass<1>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
+        case 2: psd_update_pass<2>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
+        case 3: psd_update_pass<3>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
+        case 4: psd_update_pass<4>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
+        default: psd_update_pass<5>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break; // K2 <= 92: 46^2 = 2116 <= 5 * 512
         }
         __syncthreads();
       }
