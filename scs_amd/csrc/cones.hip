@@ -396,6 +396,29 @@ __device__ __forceinline__ real psd_unpack_entry(const real *X, int k, bool cplx
   return v;
 }
 
+// (c, s) of the Jacobi rotation that annihilates a_pq: t = sgn(d) b / (|d| + h), h = sqrt(d^2 + b^2), d = a_qq - a_pp, b = 2 a_pq,
+// c = 1 / sqrt(1 + t^2), s = t c.  Written through the identities (|d| + h)^2 + b^2 = 2 h (|d| + h) and c^2 = (h + |d|) / (2 h):
+//     q = 1 / h = rsqrt(d^2 + b^2),  u = 1/2 + |d| q / 2 = c^2,  rc = rsqrt(u),  c = u rc,  s = sgn(d) b q rc / 2
+// -- two reciprocal square roots instead of a square root, a division and a reciprocal square root in sequence: on this part each of
+// them is a Newton sequence, and the chain sits on 25 - 32 lanes between two barriers of every Jacobi step.  c^2 + s^2 = 1 holds to
+// rounding as before.  Outside the range where d^2 + b^2 is a normal number the sequential form is kept.
+__device__ __forceinline__ void jacobi_cs(real d, real b, real &c, real &s) {
+  const real g = d * d + b * b;
+  const real lo = sizeof(real) == 8 ? (real)1e-290 : (real)1e-30, hi = sizeof(real) == 8 ? (real)1e290 : (real)1e30;
+  if (g > lo && g < hi) {
+    const real q = rsqrt(g);
+    const real u = (real)0.5 + (real)0.5 * absval(d) * q;
+    const real rc = rsqrt(u);
+    c = u * rc;
+    s = (d >= 0 ? b : -b) * ((real)0.5 * q * rc);
+  } else {
+    const real h = sqrt(g);
+    const real t = (d >= 0 ? b : -b) / (absval(d) + h);
+    c = rsqrt(t * t + (real)1);
+    s = t * c;
+  }
+}
+
 // One update pass of the LDS Jacobi kernel, A <- J' A J over 2x2 blocks (rows of pair P, columns of pair Q) and V <- V J over
 // (row, pair) items (there are exactly twice as many of those): every lane owns up to NB blocks and 2 NB row pairs and asks for all
 // its tables, then all its operands, before it computes -- the LDS round trips of a lane's items overlap instead of queueing behind
@@ -594,10 +617,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
             // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written
             // without the first division: t = sgn(d) b / (|d| + sqrt(d^2 + b^2)), d = aqq - app, b = 2 apq
             const real d = A[MI(q, q)] - A[MI(p, p)], b = (real)2 * apq;
-            const real h = sqrt(d * d + b * b);
-            const real t = (d >= 0 ? b : -b) / (absval(d) + h);
-            c = rsqrt(t * t + (real)1);
-            s = t * c;
+            jacobi_cs(d, b, c, s);
             rot_any[par] = 1;
           }
           rot_pq[i] = make_int2(p, q);

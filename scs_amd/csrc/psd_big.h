@@ -130,10 +130,7 @@ __device__ __forceinline__ void bp_rotation(const real *Aold, size_t ld, int i, 
   if (q < k && aa > thr) {
     // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the first division
     const real d = aqq - app, bb = (real)2 * apq;
-    const real h = sqrt(d * d + bb * bb);
-    const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
-    c = rsqrt(t * t + (real)1);
-    s = t * c;
+    jacobi_cs(d, bb, c, s);
   }
   pq = make_int2(p, q);
   cs = RotCS{c, s};
@@ -359,10 +356,7 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
       if (real_pair) offmax = aa > offmax ? aa : offmax;
       if (real_pair && aa > thr) {
         const real d = S[q * BJ_ILD + q] - S[p * BJ_ILD + p], bb = (real)2 * apq;
-        const real h = sqrt(d * d + bb * bb);
-        const real t = (d >= 0 ? bb : -bb) / (absval(d) + h);
-        c = rsqrt(t * t + (real)1);
-        s = t * c;
+        jacobi_cs(d, bb, c, s);
         rot_any[par] = 1;
       }
       rot_pq[i] = make_int2(p, q);
