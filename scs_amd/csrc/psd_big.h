@@ -554,10 +554,11 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
 // closes a sweep for every block; *remaining = blocks still iterating
 __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int rem = 0;
+  int rem = 0, worked = 0;
   for (int b = 0; b < B.nbig; ++b) {
     BigPsdCtl *c = B.ctl + b;
     if (c->done) continue;
+    worked = 1;
     c->sweeps += 1;
     if (bp_from_bits(c->offmax_bits) <= c->thr) {
       c->done = 1;
@@ -569,7 +570,8 @@ __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
     }
     c->offmax_bits = 0ull;
   }
-  *remaining = rem;
+  remaining[0] = rem;
+  remaining[1] += worked; // sweeps of this projection in which some block still iterated (the host sizes its next batch from it)
 }
 
 // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044), in place
@@ -665,9 +667,10 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_gram(BigPsdView B, real *x) {
 #endif
 }
 
-__global__ void k_bp_set_kraw(BigPsdView B) {
+__global__ void k_bp_set_kraw(BigPsdView B, int *remaining) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B.nbig) B.ctl[b].kraw = B.psd_k[B.id[b]];
+  if (b == 0) remaining[1] = 0;
 }
 
 // C = L' R for K2 x K2 column-major matrices (both operands contiguous along the summation index): the two products
@@ -747,10 +750,11 @@ struct BigPsd {
   long long sweeps_total = 0, projections = 0;
   bool warm_ok = true;
   bool blocked = true;       // tournament over 32-wide block columns with MFMA updates (k_bj_*); false: single columns (k_bp_step)
+  int sweeps_hint = 0;       // sweeps the previous projection needed: that many minus one are enqueued before the first read-back
   bool cross = true;         // blocked: every index pair once per sweep (within pass + cross-pair tournament steps), see bj_pair_sched
   DevBuf<real> Qbuf, Sbuf;   // blocked: per (block, block-column pair) the 64 x 64 factor Q and rotated subproblem S'
   DevBuf<int> Qflag;         // ... and whether the pair's inner sweep rotated at all
-  void reset_warm_start() { calls = 0; have_basis = false; }
+  void reset_warm_start() { calls = 0; have_basis = false; sweeps_hint = 0; }
 
   // pk: signed orders of all PSD blocks (negative = complex embedding order); blocks above lds_kmax are taken
   void init(const std::vector<int> &pk, int lds_kmax, hipStream_t st) {
@@ -788,7 +792,7 @@ struct BigPsd {
     have_basis = false;
     calls = 0;
     ctl.alloc(nbig);
-    remaining.alloc(1);
+    remaining.alloc(2);
     HIP_CHECK(hipStreamSynchronize(st));
   }
 
@@ -805,7 +809,7 @@ struct BigPsd {
     const bool warm = warm_ok && have_basis && (calls % PSD_WARM_RESET) != 0;
     ++calls;
     const size_t mat_bytes = (size_t)nbig * ld * ld * sizeof(real);
-    hipLaunchKernelGGL(k_bp_set_kraw, dim3((nbig + 63) / 64), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(k_bp_set_kraw, dim3((nbig + 63) / 64), dim3(64), 0, st, B, remaining.p);
     hipLaunchKernelGGL(k_bp_unpack, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B, x, warm ? 0 : 1, blocked ? 1 : 0);
     if (warm) {
       const long long T16 = (ld + 15) / 16;
@@ -816,12 +820,18 @@ struct BigPsd {
       hipLaunchKernelGGL(k_bp_symm, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B);
     }
     hipLaunchKernelGGL(k_bp_norm, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B);
-    int h_rem = nbig;
+    int h_rem[2] = {nbig, 0};
     long long gstep = 0; // launches so far: the copy of A a block is in alternates with the steps IT took (ctl.cur)
     const long long sweeps_before = sweeps_total;
     const int nbc_max = ld / BJ_B, npmax = ld / BJ_W;
     const int g_upd = npmax * npmax + npmax * (ld / BJ_W); // A tiles + V tiles of the largest block
-    for (int sweep = 0; sweep < PSD_MAX_SWEEPS && h_rem > 0; ++sweep) {
+    // Sweeps are enqueued in batches: as many as the previous projection of these blocks needed, minus one, before the first
+    // read-back, then one at a time (consecutive ADMM iterates need nearly the same count; a block that has converged makes every
+    // later launch return at once, as in the PCG loop; the sweep cap of cones.c:1031 is enforced on the device).  One host
+    // round trip per sweep cost 50 - 100 us -- a third of a projection of 32 blocks of order 100.
+    int enq = 0, batch = std::max(1, std::min(sweeps_hint - 1, 8)); // (capped: the projection after a cold start needs far fewer)
+    while (h_rem[0] > 0 && enq < PSD_MAX_SWEEPS + 4) {
+     for (int bsw = 0; bsw < batch; ++bsw, ++enq) {
       if (blocked) {
         const int osteps = cross ? nbc_max : nbc_max - 1; // cross schedule: the within pass, then the tournament steps
         for (int step = 0; step < osteps; ++step, ++gstep) {
@@ -836,10 +846,13 @@ struct BigPsd {
           hipLaunchKernelGGL(k_bp_step, dim3(g_step, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1) | (step << 1));
       }
       hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p);
-      HIP_CHECK(hipMemcpyAsync(&h_rem, remaining.p, sizeof(int), hipMemcpyDeviceToHost, st));
+     }
+      HIP_CHECK(hipMemcpyAsync(h_rem, remaining.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
-      ++sweeps_total;
+      batch = 1;
     }
+    sweeps_total += h_rem[1];
+    sweeps_hint = h_rem[1];
     ++projections;
     static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
     if (debug) fprintf(stderr, "[scs_amd psd_big] projection %lld: %s start, sweeps so far %lld (this one %lld)\n", projections, warm ? "warm" : "cold", sweeps_total, sweeps_total - sweeps_before);
