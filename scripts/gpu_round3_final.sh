@@ -13,6 +13,6 @@ import json
 d=json.load(open("$OUT/bench_default.json"))
 print("value", d["value"], "us/cg", d["us_per_cg_iter"], "frac", d["roofline"]["frac"], "batch", d["batch"]["admm_iters_per_s"])
 print("cpu1", d["cpu_baseline"]["value"], "omp", [(l["cores"], l["value"]) for l in d["cpu_baseline_omp"]["legs"]])
-s=d["secondary"]; print("sdp", s["configs2_sdp"]["ms_per_projection"], "fp32", s["configs4_fp32"].get("status"), s["configs4_fp32"].get("time_to_eps_s"), "loc", s["locality_variant"]["roofline"]["frac"])
+s=d["secondary"]; print("sdp", s["configs2_sdp"]["ms_per_projection"], "fp32", s["configs4_fp32"].get("status"), s["configs4_fp32"].get("time_to_eps_s"), "loc", {k: round(v["roofline"]["frac"], 3) for k, v in s["locality_variant"].items()})
 PY
-bash scripts/profile_bench.sh r3 > $OUT/profile.log 2>&1; tail -30 $OUT/profile.log | cut -c1-200
+# (scripts/profile_bench.sh r3 ran in an earlier call: profiles/r3_pmc_traffic.json)
