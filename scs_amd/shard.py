@@ -30,29 +30,62 @@ def slab(m, world, rank):
     return r0, r0 + base + (1 if rank < extra else 0)
 
 
-class ShardedLinSys:
-    """A: scipy CSC (m x n) -- every rank passes the same matrix (or at least its own rows); diag_r = [R_x (n); R_y (m)]."""
+class HipSlabOps:
+    """the slab's operator pieces on the GPU: a B1 workspace of libscsamd_linsys.so driven through its device-pointer entries"""
 
-    def __init__(self, A, diag_r, dist=None, device="cuda", lib=None):
+    def __init__(self, Ar, rx_share, ry, lib=None):
+        import torch
+        self.torch = torch
+        self.lib = lib or capi.load("libscsamd_linsys.so")
+        self.T = T = self.lib._scs_types
+        mr, n = Ar.shape
+        self.prob = capi.Problem(Ar, np.zeros(mr), np.zeros(n), dict(l=mr), T=T)
+        local = np.concatenate([rx_share, ry]).astype(T.np_float)
+        self.w = self.lib.scs_init_lin_sys_work(C.byref(self.prob.matA), None, local.ctypes.data_as(T.fp))
+        if not self.w:
+            raise RuntimeError("scs_init_lin_sys_work failed on the row slab")
+
+    def _call(self, fn, src, dst):
+        self.torch.cuda.synchronize()  # torch's stream and the workspace's stream are different streams: functional form
+        if fn(self.w, src.data_ptr(), dst.data_ptr()) != 0:
+            raise RuntimeError("device operator call failed")
+        if self.lib.scs_amd_linsys_sync(self.w) != 0:
+            raise RuntimeError("stream synchronisation failed")
+
+    def mat_vec(self, x, y):
+        self._call(self.lib.scs_amd_linsys_mat_vec_dev, x, y)
+
+    def mul_a(self, x, y):
+        self._call(self.lib.scs_amd_linsys_mul_a_dev, x, y)
+
+    def mul_at(self, y, x):
+        self._call(self.lib.scs_amd_linsys_mul_at_dev, y, x)
+
+    def close(self):
+        if self.w:
+            self.lib.scs_free_lin_sys_work(self.w)
+            self.w = None
+
+
+class ShardedLinSys:
+    """A: scipy CSC (m x n) -- every rank passes the same matrix (or at least its own rows); diag_r = [R_x (n); R_y (m)].
+    `ops_factory(Ar, rx_share, ry)` builds the slab's operator pieces (default: HipSlabOps, the GPU; the CPU-hosted gloo test
+    of the collective / PCG logic injects a scipy stand-in)."""
+
+    def __init__(self, A, diag_r, dist=None, device="cuda", lib=None, ops_factory=None, dtype=np.float64):
         import scipy.sparse as sp
         import torch
         self.torch, self.dist, self.device = torch, dist, device
         self.world = 1 if dist is None else dist.get_world_size()
         self.rank = 0 if dist is None else dist.get_rank()
-        self.lib = lib or capi.load("libscsamd_linsys.so")
-        self.T = self.lib._scs_types
         self.m, self.n = A.shape
         self.r0, self.r1 = slab(self.m, self.world, self.rank)
         Ar = sp.csc_matrix(sp.csr_matrix(A)[self.r0:self.r1, :])
-        self.prob = capi.Problem(Ar, np.zeros(self.r1 - self.r0), np.zeros(self.n), dict(l=self.r1 - self.r0), T=self.T)
-        f = self.T.np_float
+        f = dtype
         diag_r = np.asarray(diag_r, dtype=f)
         self.rx = diag_r[:self.n].copy()
         self.ry = diag_r[self.n + self.r0:self.n + self.r1].copy()
-        local = np.concatenate([self.rx / self.world, self.ry]).astype(f)
-        self.w = self.lib.scs_init_lin_sys_work(C.byref(self.prob.matA), None, local.ctypes.data_as(self.T.fp))
-        if not self.w:
-            raise RuntimeError("scs_init_lin_sys_work failed on the row slab")
+        self.ops = (ops_factory or (lambda a, b, c: HipSlabOps(a, b, c, lib)))(Ar, self.rx / self.world, self.ry)
         td = torch.float64 if f is np.float64 else torch.float32
         self.td = td
         # Jacobi preconditioner (private.c:50-82): diag(G) = R_x + sum_r diag(A_r' R_r^-1 A_r)
@@ -77,17 +110,10 @@ class ShardedLinSys:
             t.copy_(h)
         return t
 
-    def _call(self, fn, src, dst):
-        self.torch.cuda.synchronize()  # torch's stream and the workspace's stream are different streams: functional form
-        if fn(self.w, src.data_ptr(), dst.data_ptr()) != 0:
-            raise RuntimeError("device operator call failed")
-        if self.lib.scs_amd_linsys_sync(self.w) != 0:
-            raise RuntimeError("stream synchronisation failed")
-
     def G(self, x):
         """G x, the same vector on every rank"""
         y = self.torch.empty_like(x)
-        self._call(self.lib.scs_amd_linsys_mat_vec_dev, x, y)
+        self.ops.mat_vec(x, y)
         self.allreduce_calls += 1
         return self._allreduce(y)
 
@@ -102,7 +128,7 @@ class ShardedLinSys:
         bx = torch.tensor(b[:n], dtype=td, device=dev)
         by = torch.tensor(b[n + self.r0:n + self.r1], dtype=td, device=dev)
         t = torch.empty(n, dtype=td, device=dev)
-        self._call(self.lib.scs_amd_linsys_mul_at_dev, by / self.ry_d, t)  # A_r' R_r^-1 r_y
+        self.ops.mul_at(by / self.ry_d, t)  # A_r' R_r^-1 r_y
         bx = bx + self._allreduce(t)
         if s is not None:
             x = torch.tensor(np.asarray(s), dtype=td, device=dev)
@@ -130,7 +156,7 @@ class ShardedLinSys:
                 p = z + (ztr / ztr_prev) * p
         self.cg_iters += its
         ax = torch.empty(self.r1 - self.r0, dtype=td, device=dev)
-        self._call(self.lib.scs_amd_linsys_mul_a_dev, x, ax)
+        self.ops.mul_a(x, ax)
         y = (ax - by) / self.ry_d  # private.c:313-317
         return x.cpu().numpy(), y.cpu().numpy()
 
@@ -143,6 +169,4 @@ class ShardedLinSys:
         return np.concatenate(parts)
 
     def close(self):
-        if self.w:
-            self.lib.scs_free_lin_sys_work(self.w)
-            self.w = None
+        self.ops.close()

@@ -150,3 +150,22 @@ def test_row_slabs_of_the_sharded_linear_system_cover_every_row_once():
         assert all(a[1] == b[0] for a, b in zip(slabs[:-1], slabs[1:]))
         sizes = [b - a for a, b in slabs]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_row_sharded_pcg_over_two_gloo_ranks():
+    """world_size 2 over gloo on CPU: the data-path collective of the row-sharded linear solve (one all-reduce of an n-vector
+    per CG iteration) and its PCG logic, the slab products played by scipy; checked against a sparse direct solve of the KKT system"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29641", os.path.join(root, "tests", "shard_cpu_worker.py")], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("SHARDCPU ")][0][9:])
+    assert d["world"] == 2 and d["rows"] == [0, 401]
+    assert d["cg_iters"] > 10 and d["allreduce_calls"] >= d["cg_iters"]
+    assert d["err"] <= 1e-9, d
