@@ -1,0 +1,148 @@
+"""A numpy restatement of the SCHEDULE of the blocked Jacobi iteration for PSD blocks beyond the LDS path
+(scs_amd/csrc/psd_big.h: `bj_pair`, `bj_pair_sched`, `bj_inner_pair`, `k_bj_inner`, `k_bj_update`) -- test infrastructure, CPU
+only: tile-level, not lane-level.  It pins what the kernels' orchestration relies on:
+
+ * the tournament over block columns pairs every two block columns exactly once per sweep and covers all columns in every step;
+ * the every-pair-once schedule (a within-block pass, then cross pairs only) rotates every index pair exactly once per sweep;
+ * with the update as the kernels do it (diagonal tile = the inner sweep's S', other tiles Q_P' A[P,Q] Q_Q, V[:,Q] Q_Q, untouched
+   tiles copied, padding rows / columns never rotated) the iteration converges to the eigen-decomposition: reconstruction and
+   eigenvalues to 1e-11, orthogonality to 1e-12, in about ten sweeps -- the numbers DESIGN.md quotes for this schedule.
+The GPU kernels themselves are compared with LAPACK through the reference in tests/test_cones_shim_gpu.py."""
+import itertools
+
+import numpy as np
+import pytest
+
+B, W = 32, 64
+
+
+def bj_pair(i, step, nbc):
+    I = 0 if i == 0 else 1 + ((i - 1 + step) % (nbc - 1))
+    J = 1 + ((nbc - 2 - i + step) % (nbc - 1))
+    return (I, J) if I < J else (J, I)
+
+
+def bj_pair_sched(i, ostep, nbc, cross):
+    if not cross:
+        return bj_pair(i, ostep, nbc)
+    return (2 * i, 2 * i + 1) if ostep == 0 else bj_pair(i, ostep - 1, nbc)
+
+
+def bj_inner_pair(i, st, kind):
+    if kind == 2:
+        return i, B + ((i + st) & (B - 1))
+    n, j, off = (B, i & (B // 2 - 1), B if i >= B // 2 else 0) if kind == 1 else (W, i, 0)
+    p = 0 if j == 0 else 1 + ((j - 1 + st) % (n - 1))
+    q = 1 + ((n - 2 - j + st) % (n - 1))
+    p, q = (p, q) if p < q else (q, p)
+    return p + off, q + off
+
+
+def gidx(IJ):
+    return np.r_[IJ[0] * B:(IJ[0] + 1) * B, IJ[1] * B:(IJ[1] + 1) * B]
+
+
+@pytest.mark.parametrize("nbc", [2, 4, 6, 8, 32])
+def test_block_column_tournament_meets_every_pair_once_and_covers_all_columns(nbc):
+    met = set()
+    for step in range(nbc - 1):
+        pairs = [bj_pair(i, step, nbc) for i in range(nbc // 2)]
+        assert sorted(itertools.chain.from_iterable(pairs)) == list(range(nbc))
+        for pr in pairs:
+            assert pr not in met
+            met.add(pr)
+    assert len(met) == nbc * (nbc - 1) // 2
+
+
+def test_every_pair_once_schedule_rotates_every_index_pair_exactly_once_per_sweep():
+    nbc = 6
+    seen = {}
+    for ostep in range(nbc):  # the within pass, then the nbc - 1 tournament steps
+        kind = 1 if ostep == 0 else 2
+        for pi in range(nbc // 2):
+            g = gidx(bj_pair_sched(pi, ostep, nbc, True))
+            for st in range(B - 1 if kind == 1 else B):
+                pairs = [bj_inner_pair(i, st, kind) for i in range(B)]
+                assert sorted(itertools.chain.from_iterable(pairs)) == list(range(W))  # 32 disjoint pairs per inner step
+                for p, q in pairs:
+                    key = (int(g[p]), int(g[q]))
+                    assert key[0] < key[1]
+                    seen[key] = seen.get(key, 0) + 1
+    K = nbc * B
+    assert len(seen) == K * (K - 1) // 2 and set(seen.values()) == {1}
+
+
+def _inner(S, g, k, thr, kind):
+    S, Q, offmax, rotated = S.copy(), np.eye(W), 0.0, False
+    for st in range({0: W - 1, 1: B - 1, 2: B}[kind]):
+        J, rot = np.eye(W), []
+        for i in range(B):
+            p, q = bj_inner_pair(i, st, kind)
+            apq = S[p, q]
+            if g[q] < k:
+                offmax = max(offmax, abs(apq))
+                if abs(apq) > thr:
+                    d, b = S[q, q] - S[p, p], 2 * apq
+                    qq = 1 / np.sqrt(d * d + b * b)          # the two-rsqrt form of cones.hip `jacobi_cs`
+                    u = 0.5 + 0.5 * abs(d) * qq
+                    rc = 1 / np.sqrt(u)
+                    c, s = u * rc, (b if d >= 0 else -b) * 0.5 * qq * rc
+                    J[p, p] = J[q, q] = c
+                    J[p, q], J[q, p] = s, -s
+                    rot.append((p, q))
+        if rot:
+            rotated = True
+            S = J.T @ S @ J
+            for p, q in rot:
+                S[p, q] = S[q, p] = 0.0   # a rotated pair's own entry: exact zero
+            Q = Q @ J
+    return Q, S, rotated, offmax
+
+
+def _project(Ain, k, cross):
+    K64 = (k + W - 1) // W * W
+    nbc, npairs = K64 // B, K64 // W
+    A = [np.zeros((K64, K64)), np.zeros((K64, K64))]
+    A[0][:k, :k] = Ain
+    V, cur, thr = np.eye(K64), 0, 1e-15 * np.linalg.norm(Ain) / k
+    for sweep in range(1, 31):
+        off = 0.0
+        for ostep in range(nbc if cross else nbc - 1):
+            kind = 0 if not cross else (1 if ostep == 0 else 2)
+            old, new = A[cur], A[cur ^ 1]
+            pairs = [gidx(bj_pair_sched(pi, ostep, nbc, cross)) for pi in range(npairs)]
+            res = [_inner(old[np.ix_(g, g)], g, k, thr, kind) for g in pairs]
+            off = max([off] + [r[3] for r in res])
+            for P in range(npairs):
+                for Qp in range(npairs):
+                    gp, gq, fP, fQ = pairs[P], pairs[Qp], res[P][2], res[Qp][2]
+                    if P == Qp and fP:
+                        new[np.ix_(gp, gq)] = res[P][1]
+                    elif not fP and not fQ:
+                        new[np.ix_(gp, gq)] = old[np.ix_(gp, gq)]
+                    else:
+                        QP = res[P][0] if fP else np.eye(W)
+                        QQ = res[Qp][0] if fQ else np.eye(W)
+                        new[np.ix_(gp, gq)] = QP.T @ (old[np.ix_(gp, gq)] @ QQ)
+            for Qp in range(npairs):
+                if res[Qp][2]:
+                    V[:, pairs[Qp]] = V[:, pairs[Qp]] @ res[Qp][0]
+            cur ^= 1
+        if off <= thr:
+            return A[cur], V, sweep
+    return A[cur], V, 31
+
+
+@pytest.mark.parametrize("k,cross", [(100, True), (100, False), (131, True)])
+def test_emulated_blocked_iteration_converges_to_the_eigen_decomposition(k, cross):
+    rng = np.random.default_rng(k)
+    M = rng.standard_normal((k, k))
+    Ain = (M + M.T) / 2
+    D, V, sweeps = _project(Ain, k, cross)
+    lam, Vk = np.diag(D)[:k], V[:k, :k]
+    assert sweeps <= 13
+    assert np.abs((Vk * lam) @ Vk.T - Ain).max() <= 1e-11
+    assert np.abs(np.sort(lam) - np.linalg.eigvalsh(Ain)).max() <= 1e-11
+    assert np.abs(Vk.T @ Vk - np.eye(k)).max() <= 1e-12
+    if V.shape[0] > k:  # padding rows / columns were never rotated
+        assert np.abs(V[k:, :k]).max() == 0.0 and np.abs(V[:k, k:]).max() == 0.0
