@@ -126,7 +126,7 @@ def test_fp32_at_5e5_linear_solve_and_capped_window_against_fp32_reference():
         system (libscsamd_linsys.so at tol 1e-12): ours must be as close to it as the reference's is (within 2x), and both
         within what tol 1e-4 on a system with lambda_min ~ 1e-2 allows;
     (ii) a window of ADMM iterations, capped identically on both sides (the fp32 reference needs seconds per iteration
-        here): same iteration count, objectives within 5e-2 of their scale, residuals within 2x -- inexact fp32 CG with
+        here): same iteration count, objectives within 1e-2 of their scale, residuals within 5 % -- inexact fp32 CG with
         different summation orders, DESIGN.md section 4 (the fp64 builds get 1e-6 with exact CG; CG_BEST_TOL = 1e-12 is out of
         reach of fp32 arithmetic, so there is no exact-CG fp32 reference to compare trajectories with)."""
     import ctypes as C
@@ -156,8 +156,9 @@ def test_fp32_at_5e5_linear_solve_and_capped_window_against_fp32_reference():
     scale = np.abs(sols["f64"][:n]).max()
     ea = np.abs(sols["amd"][:n] - sols["f64"][:n]).max() / scale
     er = np.abs(sols["ref"][:n] - sols["f64"][:n]).max() / scale
-    assert ea <= 2e-2 and er <= 2e-2, (ea, er)       # tol / lambda_min, with lambda_min of R_x + A' R_y^-1 A ~ 1e-2
-    assert ea <= 2.0 * er + 1e-4, (ea, er)           # as accurate as the reference's own fp32 solve
+    print(f"[fp32 5e5] linear solve vs fp64 truth: ours {ea:.3e}, reference {er:.3e}")
+    assert ea <= 2e-4 and er <= 2e-4, (ea, er)       # measured 2.1e-5 (ours) and 2.6e-5 (reference): fp32 rounding of a tol = 1e-4 solve
+    assert ea <= 2.0 * er + 1e-6, (ea, er)           # as accurate as the reference's own fp32 solve
     # (ii)
     iters = 8
     kw = dict(verbose=0, acceleration_lookback=0, eps_abs=1e-3, eps_rel=1e-3, max_iters=iters)
@@ -165,10 +166,13 @@ def test_fp32_at_5e5_linear_solve_and_capped_window_against_fp32_reference():
     ia, ir = ra["info"], rr["info"]
     assert ia["iter"] == ir["iter"] == iters
     sc = max(1.0, abs(ir["pobj"]), abs(ir["dobj"]))
-    assert abs(ia["pobj"] - ir["pobj"]) <= 5e-2 * sc, (ia["pobj"], ir["pobj"])
-    assert abs(ia["dobj"] - ir["dobj"]) <= 5e-2 * sc, (ia["dobj"], ir["dobj"])
+    print(f"[fp32 5e5] after {iters} iterations: pobj {ia['pobj']:.6g} vs {ir['pobj']:.6g}, dobj {ia['dobj']:.6g} vs {ir['dobj']:.6g} (scale {sc:.3g}); "
+          f"res_pri {ia['res_pri']:.4g} vs {ir['res_pri']:.4g}, res_dual {ia['res_dual']:.4g} vs {ir['res_dual']:.4g}")
+    # measured: objectives 2.2e-3 / 4.3e-4 of their scale apart, residuals equal to 4 / 3 digits (inexact fp32 CG, other summation orders)
+    assert abs(ia["pobj"] - ir["pobj"]) <= 1e-2 * sc, (ia["pobj"], ir["pobj"])
+    assert abs(ia["dobj"] - ir["dobj"]) <= 1e-2 * sc, (ia["dobj"], ir["dobj"])
     for k in ("res_pri", "res_dual"):
-        assert 0.5 <= ia[k] / ir[k] <= 2.0, (k, ia[k], ir[k])
+        assert 0.95 <= ia[k] / ir[k] <= 1.05, (k, ia[k], ir[k])
 
 
 def test_reference_random_socp_prob_program_over_our_library():
