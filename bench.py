@@ -141,8 +141,11 @@ def _cpu_worker(spec):
     for ln in lines[1:]:
         f = ln.rstrip(",").split(",")
         t_after.setdefault(int(f[ci]), float(f[ct]))  # first row of an iteration number (the final row repeats the last)
+    last = lines[-1].rstrip(",").split(",")  # the state after i0 + k iterations, as the reference logged it
+    state = {nm: float(last[names.index(nm)]) for nm in ("res_pri", "res_dual", "gap", "pobj", "dobj") if nm in names}
+    state["iter"] = int(float(last[ci]))
     out = dict(iter=r["iter"], solve_s=r["solve_time"] / 1e3, lin_sys_s=r["lin_sys_time"] / 1e3, setup_s=r["setup_time"] / 1e3,
-               flavour=flavour, threads=threads, n=n, i0=i0, k=k, wall_s=time.time() - t0)
+               flavour=flavour, threads=threads, n=n, i0=i0, k=k, wall_s=time.time() - t0, state_after_window=state)
     if i0 >= 1 and (i0 - 1) in t_after and (i0 + k - 1) in t_after:
         out["window_s"] = t_after[i0 + k - 1] - t_after[i0 - 1]
         out["its_per_s"] = k / out["window_s"] if out["window_s"] > 0 else None
@@ -200,6 +203,7 @@ def cpu_leg(args, n, threads, handle, timeout, gpu_window_its_per_s=None, gpu_cg
     r = _cpu_collect(handle, timeout)
     host = dict(host_cores=os.cpu_count(), cpu_model=_cpu_model())
     if r.get("its_per_s"):
+        host["state_after_window"] = r.get("state_after_window")
         out = dict(value=r["its_per_s"], unit="ADMM iters/sec", cores=threads, kind="reference",
                    sample=(f"reference {r['flavour']} (linsys/cpu/indirect, {threads} thread(s)) on the SAME generator and "
                            f"size (n={n}, m={2*n}, nnz={n*args.col_nnz}): ADMM iterations {r['window'][0]}..{r['window'][1]} "
@@ -634,7 +638,7 @@ def main():
         dist.all_gather(recs, rec)
 
     # ---- GPU rate over the CPU baseline's iteration window (rank 0, N = 1) -------------------------
-    gpu_win = gpu_cg_win = None
+    gpu_win = gpu_cg_win = gpu_win_state = None
     want_cpu = world == 1 and not args.no_cpu_baseline and args.dtype == "f64" and not stub
     if want_cpu:
         S.begin()
@@ -650,7 +654,7 @@ def main():
                          "warnings below (if any) belong to that deliberately unconverged run, not to the headline solve\n"
                          % (args.cpu_window_i0 + args.cpu_window_iters))
         sys.stderr.flush()
-        S.end()
+        gpu_win_state = S.end()
         gpu_win = args.cpu_window_iters / dt
         gpu_cg_win = (sb["cg_iters"] - sa["cg_iters"]) / float(args.cpu_window_iters)
     S.close()  # free the headline problem before the side workloads
@@ -749,6 +753,22 @@ def main():
             # the OpenMP legs start while the 1-thread leg is still finishing (one extra core does not disturb them)
             out["cpu_baseline_omp"] = cpu_omp_sweep(args, n, cpu_early, gpu_win)
             out["cpu_baseline"] = cpu_leg(args, n, 1, cpu1, args.cpu_baseline_timeout, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
+            ref_state = (out["cpu_baseline"] or {}).pop("state_after_window", None)
+            if ref_state and gpu_win_state and ref_state.get("iter") == gpu_win_state["iter"]:
+                # the SAME problem, the SAME number of ADMM iterations under the reference's default (inexact-CG) schedule on both
+                # sides: how far apart the two trajectories are at the headline size (they differ by O(CG tolerance) per
+                # iteration by construction -- DESIGN.md section 4 -- so this is a closeness figure, not an identity)
+                keys = ("res_pri", "res_dual", "gap", "pobj", "dobj")
+                scale = max(1.0, abs(ref_state["pobj"]), abs(ref_state["dobj"]))
+                out["parity_window"] = dict(
+                    iter=ref_state["iter"], gpu={k: gpu_win_state[k] for k in keys}, cpu_reference={k: ref_state[k] for k in keys},
+                    rel_diff=dict(res_pri=abs(gpu_win_state["res_pri"] - ref_state["res_pri"]) / max(abs(ref_state["res_pri"]), 1e-300),
+                                  res_dual=abs(gpu_win_state["res_dual"] - ref_state["res_dual"]) / max(abs(ref_state["res_dual"]), 1e-300),
+                                  pobj=abs(gpu_win_state["pobj"] - ref_state["pobj"]) / scale,
+                                  dobj=abs(gpu_win_state["dobj"] - ref_state["dobj"]) / scale),
+                    note="headline problem, default inexact-CG schedule on both sides, state after the CPU window's last iteration "
+                         "(GPU: scs_amd_solve_end of the capped re-run; reference: last row of its log_csv_filename log); objectives "
+                         "relative to max(1, |pobj|, |dobj|)")
         else:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())

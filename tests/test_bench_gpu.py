@@ -89,3 +89,5 @@ def test_side_workloads_of_the_default_line_at_reduced_sizes():
         assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
         legs = d["cpu_baseline_omp"]["legs"]
         assert legs and legs[0]["cores"] == 4 and legs[0]["value"] > 0
+        pw = d["parity_window"]  # same problem, same iteration count, default schedule on both sides: close, not identical
+        assert pw["iter"] == 3 and all(v < 0.25 for v in pw["rel_diff"].values()), pw
