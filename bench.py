@@ -271,8 +271,8 @@ class HipSolver:
         self.cone = pr["cone"]
         self.prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
         self.t_gen = time.time() - t0
-        st = capi.default_settings(self.lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters, eps_abs=eps,
-                                   eps_rel=eps)
+        self.st = st = capi.default_settings(self.lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters, eps_abs=eps,
+                                             eps_rel=eps)
         t0 = time.time()
         self.w = self.lib.scs_init(C.byref(self.prob.data), C.byref(self.prob.k), C.byref(st))
         if not self.w:
@@ -284,6 +284,14 @@ class HipSolver:
         self.sol = T.ScsSolution(self.x.ctypes.data_as(T.fp), self.y.ctypes.data_as(T.fp), self.s.ctypes.data_as(T.fp))
         self.info = T.ScsInfo()
         self.max_iters = args.max_iters
+
+    def reinit(self):
+        """a fresh workspace for the same problem: a second scs_solve on a used workspace starts from the scale the first one
+        adapted to (as in the reference), which is not the state a cold CPU run starts from"""
+        self.lib.scs_finish(self.w)
+        self.w = self.lib.scs_init(C.byref(self.prob.data), C.byref(self.prob.k), C.byref(self.st))
+        if not self.w:
+            raise SystemExit("scs_init failed")
 
     def begin(self):
         assert self.lib.scs_amd_solve_begin(self.w, None, 0) == 0
@@ -641,6 +649,7 @@ def main():
     gpu_win = gpu_cg_win = gpu_win_state = None
     want_cpu = world == 1 and not args.no_cpu_baseline and args.dtype == "f64" and not stub
     if want_cpu:
+        S.reinit()  # the CPU legs run the problem from a fresh scs_init: so does this window
         S.begin()
         S.steps(args.cpu_window_i0)
         sa = S.stats()
