@@ -224,6 +224,22 @@ struct alignas(16) rvec {
 };
 __device__ __forceinline__ rvec ldv(const scs_float *p, size_t iv) { return reinterpret_cast<const rvec *>(p)[iv]; }
 __device__ __forceinline__ void stv(scs_float *p, size_t iv, const rvec &x) { reinterpret_cast<rvec *>(p)[iv] = x; }
+// the same with the non-temporal cache policy (streams that nothing re-reads soon: they should not push the matrix streams and
+// the gathered vectors out of L2 / the Infinity Cache)
+typedef scs_float rvec_nt __attribute__((ext_vector_type(RVW)));
+__device__ __forceinline__ rvec ldv_nt(const scs_float *p, size_t iv) {
+  const rvec_nt v = __builtin_nontemporal_load(reinterpret_cast<const rvec_nt *>(p) + iv);
+  rvec r;
+#pragma unroll
+  for (int e = 0; e < RVW; ++e) r.v[e] = v[e];
+  return r;
+}
+__device__ __forceinline__ void stv_nt(scs_float *p, size_t iv, const rvec &x) {
+  rvec_nt v;
+#pragma unroll
+  for (int e = 0; e < RVW; ++e) v[e] = x.v[e];
+  __builtin_nontemporal_store(v, reinterpret_cast<rvec_nt *>(p) + iv);
+}
 #endif // __HIPCC__
 
 } // namespace scsamd

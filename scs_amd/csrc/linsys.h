@@ -30,6 +30,7 @@ struct LinSys {
   bool own_stream = false;
   bool has_P = false;
   bool use_fused = false; // whole solve in one workgroup (small systems)
+  int nt_mode = 0;        // non-temporal policy of the update kernel's streams (SCS_AMD_VEC_NT; 0 = default policy)
   bool use_cg2 = false;   // two launches per CG iteration (n <= CG2_N_MAX): k_cg2_a + transposed product
 
   CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, re
                                                             const real *__restrict__ M, int n,
                                                             const real *part_pgp, int cnt_pgp,
                                                             real *part_ztr, real *part_max,
-                                                            const CgCtl *ctl, int parity) {
+                                                            const CgCtl *ctl, int parity, int ntm) {
   __shared__ real red[4];
   // small systems are bound by chains of dependent reads (~1 us each: the operands were written by the previous
   // kernel on other CUs): the lane's first vector chunk, the control words and the partials are all requested
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, re
     stv(z, gtid, Z);
   }
   for (int iv = gtid + gs; iv < nv; iv += gs) { // 16 B per lane per array
-    const rvec P = ldv(p, iv), G = ldv(Gp, iv), Mv = ldv(M, iv);
-    rvec X = ldv(x, iv), R = ldv(r, iv), Z;
+    const rvec P = (ntm & 2) ? ldv_nt(p, iv) : ldv(p, iv), G = (ntm & 2) ? ldv_nt(Gp, iv) : ldv(Gp, iv), Mv = ntm ? ldv_nt(M, iv) : ldv(M, iv);
+    rvec X = ntm ? ldv_nt(x, iv) : ldv(x, iv), R = ntm ? ldv_nt(r, iv) : ldv(r, iv), Z;
 #pragma unroll
     for (int e = 0; e < RVW; ++e) {
       X.v[e] += alpha * P.v[e];
@@ -209,9 +209,15 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, re
       const real a = absval(ri);
       mx = a > mx ? a : mx;
     }
-    stv(x, iv, X);
-    stv(r, iv, R);
-    stv(z, iv, Z);
+    if (ntm) {
+      stv_nt(x, iv, X);
+      stv_nt(r, iv, R);
+    } else {
+      stv(x, iv, X);
+      stv(r, iv, R);
+    }
+    if (ntm & 2) stv_nt(z, iv, Z);
+    else stv(z, iv, Z);
   }
   for (int i = nv * RVW + gtid; i < n; i += gs) {
     const real pi = p[i], gi = Gp[i];
@@ -788,6 +794,8 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     if (const char *e = getenv("SCS_AMD_FUSED")) use_fused = atoi(e) != 0;
     // below this size a CG kernel is shorter than the host's cost of launching it: replay the
     // iterations from a captured graph instead (above it launches are hidden behind the kernels)
+    nt_mode = 0;
+    if (const char *e = getenv("SCS_AMD_VEC_NT")) nt_mode = atoi(e); // measurement switch: non-temporal policy in k_cg_update
     use_graph = nnzA <= CG_GRAPH_MAX_NNZ;
     if (const char *e = getenv("SCS_AMD_GRAPH")) use_graph = atoi(e) != 0;
     // two launches per CG iteration (k_cg2_a + the transposed product): n small enough for p in LDS, no P
@@ -911,7 +919,7 @@ void LinSys::enqueue_cg_iteration(int q) {
   EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, part_pgp};
   launch_spmv(EPI_GP, At, tmp.p, Gp.p, e2, &c->cg_done);
   hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, cg_x, r.p, z.p, p.p, Gp.p, M.p, n,
-                     part_pgp, gAt, part_ztr, part_max, c, q);
+                     part_pgp, gAt, part_ztr, part_max, c, q, nt_mode);
   hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, part_ztr, part_max,
                      gv, c, q);
 }
