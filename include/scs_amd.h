@@ -20,8 +20,12 @@
  *       Host pointers in/out, identical contract to linsys/cpu/indirect
  *       (private.c:221-349): `b` is overwritten by [x; y], `s` may be NULL,
  *       0 == success, NULL on init failure.  These five symbols are also
- *       exported by scs_amd/lib/libscsamd_linsys.so (nothing else in it), which
- *       is what a reference build links instead of linsys/<backend>/private.o.
+ *       exported by scs_amd/lib/libscsamd_linsys.so (besides scs_amd_* helpers,
+ *       nothing else in it), which is what a reference build links instead of
+ *       linsys/<backend>/private.o.  Beside them, on DEVICE pointers, the pieces
+ *       of `mat_vec` (private.c:106-119) for a caller that splits one system by
+ *       rows of A across GPUs: scs_amd_linsys_mat_vec_dev / _mul_a_dev /
+ *       _mul_at_dev / _sync (declared with the instrumentation below).
  *
  *   B1' cone projection             reference include/cones.h:80-90
  *         scs_amd_cone_init  scs_amd_cone_proj_dual  scs_amd_cone_finish
