@@ -76,6 +76,11 @@ def parse():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f32 = the -DSFLOAT library (BASELINE configs[4]; residual tolerance relaxed to 1e-3)")
     ap.add_argument("--eps", type=float, default=0.0, help="eps_abs = eps_rel (default 1e-4; 1e-3 with --dtype f32)")
+    ap.add_argument("--parity-threads", type=int, default=32,
+                    help="OpenMP threads of the reference's to-termination solve of one configs[3] problem (batch.parity); 0 = skip")
+    ap.add_argument("--aa-window-threads", type=int, default=32,
+                    help="OpenMP threads of the reference's AA-on window on the headline problem (secondary.headline_aa_on.cpu_reference); 0 = skip")
+    ap.add_argument("--aa-window-iters", type=int, default=21, help="iterations 1..1+k of the AA-on CPU window (AA calls at iterations 10 and 20; the first call only fills the memory)")
     ap.add_argument("--batch-n", type=int, default=200000)
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--batch-concurrency", type=int, default=4)
@@ -97,34 +102,105 @@ def parse():
 # CPU baseline: the reference's own linsys/cpu/indirect (oracle/_ref, built from /root/reference by
 # oracle/Makefile), on the host cores, in child processes with hard timeouts.
 # ---------------------------------------------------------------------------------------------------
+def _numa_cpus():
+    """[[cpus of NUMA node 0], [cpus of node 1], ...] from sysfs; one list with every CPU if the topology is not exposed."""
+    out = []
+    try:
+        import glob
+        for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda q: int(q.rsplit("node", 1)[1])):
+            cpus = []
+            for part in open(os.path.join(d, "cpulist")).read().strip().split(","):
+                if "-" in part:
+                    a, b = part.split("-")
+                    cpus += list(range(int(a), int(b) + 1))
+                elif part:
+                    cpus.append(int(part))
+            if cpus:
+                out.append(cpus)
+    except Exception:
+        out = []
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    out = [[c for c in node if c in set(allowed)] for node in out]
+    out = [node for node in out if node]
+    return out or [allowed]
+
+
+def _pin(side):
+    """Keep the timed CPU legs ("a") and the long side legs ("b": the to-termination parity solve, the AA-on window) on
+    different NUMA nodes (halves of the CPU list on a one-node host) so that they do not share memory bandwidth."""
+    if not side or not hasattr(os, "sched_setaffinity"):
+        return None
+    nodes = _numa_cpus()
+    if len(nodes) >= 2:
+        cpus = nodes[0] if side == "a" else nodes[-1]
+    else:
+        c = nodes[0]
+        cpus = c[:max(1, len(c) // 2)] if side == "a" else c[len(c) // 2:] or c
+    try:
+        os.sched_setaffinity(0, cpus)
+        return len(cpus)
+    except Exception:
+        return None
+
+
+PARITY_COLS = ("res_pri", "res_dual", "gap", "pobj", "dobj")
+
+
+def _read_csv_rows(path):
+    """rows of a `log_csv_filename` log (src/rw.c:707-863; ours: log_csv_row in scs_amd/csrc/admm.hip) -> (names, rows of floats)"""
+    lines = open(path).read().splitlines()
+    names = lines[0].rstrip(",").split(",")
+    rows = []
+    for ln in lines[1:]:
+        f = ln.rstrip(",").split(",")
+        rows.append([float(v) if v.strip() else float("nan") for v in f[:len(names)]])
+    return names, rows
+
+
 def _cpu_worker(spec):
-    """child process: CPU only.  spec = kind:threads:n:col_nnz:seed:aa:q_fixed:i0:k
+    """child process: CPU only.  spec = kind:threads:n:col_nnz:seed:aa:q_fixed:i0:k:side
     socp: ONE run of the reference capped at i0 + k ADMM iterations with its own per-iteration CSV log switched on
     (`log_csv_filename`, src/rw.c:707-863: cumulative solve time after every iteration); the window [i0, i0 + k) is read
-    off that log.  The log costs the reference one residual evaluation per iteration (src/scs.c:1450-1454: two extra
-    products beside the ~250 of the iteration's PCG, < 2 %), and iteration 0 -- which solves its linear system to the
-    1e-12 floor -- stays outside the window."""
-    kind, threads, n, col_nnz, seed, aa, q_fixed, i0, k = spec.split(":")
+    off that log.  With the log on the reference refreshes its normalised residuals after EVERY iteration
+    (src/scs.c:1449-1454) and those norms set the next iteration's CG tolerance (src/scs.c:745-762): a logged run follows a
+    tighter tolerance schedule than an unlogged one (the reference differs from itself by 3-4 % in the residuals and -32 % in
+    lin_sys_time after 5 iterations at n=2e4).  The GPU side of every comparison with this leg therefore runs the
+    SAME schedule (scs_amd_set_residuals_every_iter / its own log_csv_filename).  The run goes through the trace flavour
+    (oracle/trace_linsys.c: the reference's backend behind a counting shim) so that the window is also known in the
+    reference's OWN CG iterations.  Iteration 0 -- which solves its linear system to the 1e-12 floor -- stays outside.
+    term: the reference (OpenMP flavour) on one problem to TERMINATION, default settings, no log."""
+    kind, threads, n, col_nnz, seed, aa, q_fixed, i0, k, side = (spec.split(":") + [""])[:10]
     threads, n, col_nnz, seed, aa, q_fixed, i0, k = map(int, (threads, n, col_nnz, seed, aa, q_fixed, i0, k))
-    flavour = "libscsindir_ref.so" if threads == 1 else "libscsindir_ref_omp.so"
+    pinned = _pin(side)
     if threads > 1:
         os.environ["OMP_NUM_THREADS"] = str(threads)  # read when libgomp initialises (first load)
         os.environ["OMP_WAIT_POLICY"] = "passive"     # active spinning makes the many tiny regions far slower
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
     from oracle import pyoracle
     from scs_amd import capi, problems
-    ref = pyoracle.load_ref(flavour)
     t0 = time.time()
     if kind == "sdp":  # configs[2]: per-projection cost of the reference's LAPACK dsyevr path
+        ref = pyoracle.load_ref("libscsindir_ref.so")
         pr = problems.random_sdp(2000, 200, 50, 1001, 10, seed=1234)
         prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
         r = capi.solve(ref, prob, verbose=0, acceleration_lookback=0, max_iters=k)["info"]
         print(json.dumps(dict(cone_ms_per_projection=r["cone_time"] / max(r["iter"], 1), iters=r["iter"],
                               wall_s=time.time() - t0)), flush=True)
         return
-    import tempfile
     pr = problems.random_socp(n, 2 * n, col_nnz, seed=seed, q_fixed=q_fixed or None)
     prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    if kind == "term":
+        flavour = "libscsindir_ref.so" if threads == 1 else "libscsindir_ref_omp.so"
+        ref = pyoracle.load_ref(flavour)
+        r = capi.solve(ref, prob, verbose=0, acceleration_lookback=aa)
+        i = r["info"]
+        print(json.dumps(dict(flavour=flavour, threads=threads, pinned_cpus=pinned, n=n, seed=seed, wall_s=time.time() - t0,
+                              info={kk: i[kk] for kk in ("status_val", "status", "iter", "pobj", "dobj", "res_pri", "res_dual", "gap",
+                                                         "solve_time", "setup_time", "scale_updates", "lin_sys_time")})), flush=True)
+        return
+    import tempfile
+    flavour = "libscsindir_ref_trace.so" if threads == 1 else "libscsindir_ref_trace_omp.so"
+    ref = pyoracle.load_ref(flavour)
     with tempfile.TemporaryDirectory() as td:
         log = os.path.join(td, "ref_log.csv")
         null_fd, out_fd = os.open(os.devnull, os.O_WRONLY), os.dup(1)
@@ -134,22 +210,29 @@ def _cpu_worker(spec):
         finally:
             C.CDLL(None).fflush(None)
             os.dup2(out_fd, 1)
-        lines = open(log).read().splitlines()
-    names = lines[0].rstrip(",").split(",")
+        names, rows = _read_csv_rows(log)
     ci, ct = names.index("iter"), names.index("time")
     t_after = {}
-    for ln in lines[1:]:
-        f = ln.rstrip(",").split(",")
-        t_after.setdefault(int(f[ci]), float(f[ct]))  # first row of an iteration number (the final row repeats the last)
-    last = lines[-1].rstrip(",").split(",")  # the state after i0 + k iterations, as the reference logged it
-    state = {nm: float(last[names.index(nm)]) for nm in ("res_pri", "res_dual", "gap", "pobj", "dobj") if nm in names}
-    state["iter"] = int(float(last[ci]))
+    for f in rows:
+        t_after.setdefault(int(f[ci]), f[ct])  # first row of an iteration number (the final row repeats the last)
+    # every logged row, the parity columns only: row j = the state after iteration j (the last row = the returned state)
+    log_rows = [dict(iter=int(f[ci]), **{nm: f[names.index(nm)] for nm in PARITY_COLS if nm in names}) for f in rows]
+    state = dict(log_rows[-1])
+    # the reference's own CG iterations: call j of scs_solve_lin_sys with a warm start = ADMM iteration j (the g solves pass s = NULL)
+    ref.oracle_trace_calls.restype = C.c_long
+    ref.oracle_trace_cg_its_of_call.argtypes = [C.c_long]
+    ref.oracle_trace_call_had_warm_start.argtypes = [C.c_long]
+    cg_by_iter = [ref.oracle_trace_cg_its_of_call(j) for j in range(ref.oracle_trace_calls()) if ref.oracle_trace_call_had_warm_start(j) == 1]
     out = dict(iter=r["iter"], solve_s=r["solve_time"] / 1e3, lin_sys_s=r["lin_sys_time"] / 1e3, setup_s=r["setup_time"] / 1e3,
-               flavour=flavour, threads=threads, n=n, i0=i0, k=k, wall_s=time.time() - t0, state_after_window=state)
+               accel_s=r["accel_time"] / 1e3, accepted_accel_steps=r["accepted_accel_steps"], rejected_accel_steps=r["rejected_accel_steps"],
+               flavour=flavour, threads=threads, pinned_cpus=pinned, n=n, i0=i0, k=k, wall_s=time.time() - t0, state_after_window=state,
+               log_rows=log_rows, cg_its_by_iter=cg_by_iter)
     if i0 >= 1 and (i0 - 1) in t_after and (i0 + k - 1) in t_after:
         out["window_s"] = t_after[i0 + k - 1] - t_after[i0 - 1]
         out["its_per_s"] = k / out["window_s"] if out["window_s"] > 0 else None
         out["window"] = [i0, i0 + k]
+        if len(cg_by_iter) >= i0 + k:
+            out["cg_its_window"] = int(sum(cg_by_iter[i0:i0 + k]))
     print(json.dumps(out), flush=True)
 
 
@@ -189,35 +272,48 @@ def _cpu_model():
     return None
 
 
-def cpu_spec(args, n, threads, i0=None, k=None):
+def cpu_spec(args, n, threads, i0=None, k=None, aa=None, side="a", kind="socp", seed=None):
     i0 = args.cpu_window_i0 if i0 is None else i0
     k = args.cpu_window_iters if k is None else k
-    return f"socp:{threads}:{n}:{args.col_nnz}:{args.seed}:{args.aa}:{args.q_fixed}:{i0}:{k}"
+    aa = args.aa if aa is None else aa
+    seed = args.seed if seed is None else seed
+    return f"{kind}:{threads}:{n}:{args.col_nnz}:{seed}:{aa}:{args.q_fixed}:{i0}:{k}:{side}"
 
 
-def cpu_leg(args, n, threads, handle, timeout, gpu_window_its_per_s=None, gpu_cg_per_it_window=None, gpu_total_cg_its=None,
-            gpu_iters_to_eps=None):
+def cpu_leg(args, n, threads, handle, timeout, gpu_window_its_per_s=None, gpu_total_cg_its=None, gpu_iters_to_eps=None,
+            gpu_cg_its_window=None):
     """One leg of the CPU baseline: the reference on the metric's own configuration (n as benchmarked), ADMM iterations
     [i0, i0 + k) read off the reference's own per-iteration log (see _cpu_worker), beside the GPU's rate over the SAME
-    iteration window.  Falls back to a small extrapolated sample if the real-size leg does not finish inside the cap."""
+    iteration window UNDER THE SAME (logged) tolerance schedule.  Falls back to a small extrapolated sample if the real-size
+    leg does not finish inside the cap."""
     r = _cpu_collect(handle, timeout)
     host = dict(host_cores=os.cpu_count(), cpu_model=_cpu_model())
     if r.get("its_per_s"):
         host["state_after_window"] = r.get("state_after_window")
+        host["log_rows"] = r.get("log_rows")
         out = dict(value=r["its_per_s"], unit="ADMM iters/sec", cores=threads, kind="reference",
-                   sample=(f"reference {r['flavour']} (linsys/cpu/indirect, {threads} thread(s)) on the SAME generator and "
+                   sample=(f"reference {r['flavour']} (linsys/cpu/indirect behind the counting shim oracle/trace_linsys.c, {threads} thread(s)"
+                           f"{', pinned to %d CPUs of one NUMA node' % r['pinned_cpus'] if r.get('pinned_cpus') else ''}) on the SAME generator and "
                            f"size (n={n}, m={2*n}, nnz={n*args.col_nnz}): ADMM iterations {r['window'][0]}..{r['window'][1]} "
                            f"in {r['window_s']:.1f} s by the reference's own per-iteration log (log_csv_filename; {r['wall_s']:.0f} s of "
                            "CPU wall incl. generation, scs_init and iteration 0)"),
-                   gpu_same_window_its_per_s=gpu_window_its_per_s, **host)
+                   schedule="logged: residual norms refreshed every iteration (src/scs.c:1449-1454) -> tighter CG tolerances (src/scs.c:745-762)",
+                   cpu_cg_its_window=r.get("cg_its_window"), cpu_cg_its_by_iter=r.get("cg_its_by_iter"),
+                   gpu_same_window_its_per_s=gpu_window_its_per_s, gpu_cg_its_window=gpu_cg_its_window, **host)
         if gpu_window_its_per_s:
+            # both sides ran iterations [i0, i0 + k) from a fresh scs_init on the SAME (logged) tolerance schedule
             out["gpu_over_cpu_same_window"] = gpu_window_its_per_s / r["its_per_s"]
-        if gpu_cg_per_it_window and gpu_total_cg_its and gpu_iters_to_eps:
-            # CG iterations per ADMM iteration fall as the solve proceeds, so scale by CG work, not by iterations
-            cpu_s_per_cg = 1.0 / (r["its_per_s"] * gpu_cg_per_it_window)
+        if r.get("cg_its_window") and gpu_total_cg_its and gpu_iters_to_eps:
+            # priced in the reference's OWN CG iterations (linsys/cpu/indirect/private.c:318 via the counting shim):
+            # seconds per CG iteration on this host x the CG iterations a solve to eps needs.  The only to-eps CG count at
+            # this size is the GPU solve's (same algorithm, unlogged default schedule); CG iterations per ADMM iteration
+            # fall as the solve proceeds, so the estimate scales by CG work, not by ADMM iterations.
+            cpu_s_per_cg = r["window_s"] / r["cg_its_window"]
+            out["cpu_s_per_cg_iter"] = cpu_s_per_cg
             out["cpu_time_to_eps_s_estimate"] = cpu_s_per_cg * gpu_total_cg_its
-            out["estimate_note"] = ("cpu seconds per CG iteration in the window x the CG iterations the GPU solve needed to reach eps "
-                                    f"({gpu_total_cg_its} over {gpu_iters_to_eps} ADMM iterations; same algorithm and tolerance schedule)")
+            out["estimate_note"] = ("the reference's seconds per CG iteration over the window (its own CG count: "
+                                    f"{r['cg_its_window']} CG iterations in {r['window_s']:.1f} s) x the CG iterations of the GPU solve to eps "
+                                    f"({gpu_total_cg_its} over {gpu_iters_to_eps} ADMM iterations)")
         return out
     if threads != 1:
         return dict(value=None, unit="ADMM iters/sec", cores=threads, kind="reference", sample=f"unavailable: {r.get('error', r)}", **host)
@@ -248,11 +344,16 @@ def cpu_omp_sweep(args, n, early, gpu_win):
         if left < 50:  # a leg needs 30 - 60 s on this host (generation, scs_init, iteration 0, the window)
             legs.append(dict(value=None, cores=thr, sample="skipped: --cpu-omp-budget spent"))
             continue
-        legs.append(cpu_leg(args, n, thr, _cpu_start(cpu_spec(args, n, thr)), min(left, args.cpu_baseline_timeout), gpu_win))
+        side = "a" if thr <= len(_numa_cpus()[0]) else ""  # legs wider than one NUMA node run unpinned
+        legs.append(cpu_leg(args, n, thr, _cpu_start(cpu_spec(args, n, thr, side=side)), min(left, args.cpu_baseline_timeout), gpu_win))
     done = [l for l in legs if l.get("value")]
     best = max(done, key=lambda l: l["value"]) if done else None
-    return dict(best=best, legs=[dict(cores=l["cores"], value=l.get("value"), sample=l.get("sample")) for l in legs],
-                note="every OpenMP leg ran alone on the host (after the GPU work), in the order listed, until the budget was spent")
+    for l in legs:  # the per-iteration rows are only reported for the 1-thread leg
+        l.pop("log_rows", None)
+        l.pop("state_after_window", None)
+    return dict(best=best, legs=[dict(cores=l["cores"], value=l.get("value"), cpu_cg_its_window=l.get("cpu_cg_its_window"), sample=l.get("sample")) for l in legs],
+                note="every OpenMP leg ran alone on its NUMA node (after the GPU work), in the order listed, until the budget was spent; "
+                     "same logged schedule and counting shim as the 1-thread leg")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -285,13 +386,21 @@ class HipSolver:
         self.info = T.ScsInfo()
         self.max_iters = args.max_iters
 
-    def reinit(self):
+    def reinit(self, log_csv=None, resid_every_iter=False):
         """a fresh workspace for the same problem: a second scs_solve on a used workspace starts from the scale the first one
-        adapted to (as in the reference), which is not the state a cold CPU run starts from"""
+        adapted to (as in the reference), which is not the state a cold CPU run starts from.  log_csv: the library's own
+        `log_csv_filename` (same cadence and columns as the reference's, src/rw.c:707-863); resid_every_iter: the logged
+        run's tolerance schedule without the host-side log (scs_amd_set_residuals_every_iter)."""
         self.lib.scs_finish(self.w)
-        self.w = self.lib.scs_init(C.byref(self.prob.data), C.byref(self.prob.k), C.byref(self.st))
+        st = self.st
+        if log_csv:
+            st = self.T.ScsSettings.from_buffer_copy(self.st)
+            self._log_name = log_csv.encode()  # keep the bytes alive
+            st.log_csv_filename = self._log_name
+        self.w = self.lib.scs_init(C.byref(self.prob.data), C.byref(self.prob.k), C.byref(st))
         if not self.w:
             raise SystemExit("scs_init failed")
+        self.lib.scs_amd_set_residuals_every_iter(self.w, 1 if resid_every_iter else 0)
 
     def begin(self):
         assert self.lib.scs_amd_solve_begin(self.w, None, 0) == 0
@@ -389,9 +498,14 @@ def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev):
         pr = problems.random_socp(desc["n"], desc["m"], desc["col_nnz"], seed=desc["seed"] + j)
         probs[j] = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
 
+    kept = {}
+
     def solve_one(j):
         lib.scs_amd_set_device(local_rank)
-        i = capi.solve(lib, probs[j], verbose=0, acceleration_lookback=0, max_iters=desc["max_iters"])["info"]
+        r = capi.solve(lib, probs[j], verbose=0, acceleration_lookback=0, max_iters=desc["max_iters"])
+        i = r["info"]
+        if j == 0:  # the problem the reference also solves to termination (batch.parity)
+            kept[0] = r
         return (j, i["status_val"], i["iter"], i["pobj"], i["dobj"], i["res_pri"], i["res_dual"], i["gap"],
                 i["solve_time"] + i["setup_time"])
 
@@ -409,10 +523,15 @@ def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     tab = batch.gather_records(recs, desc["count"], dist, dev)
     wall = float(el.item())
-    return dict(workload=f"BASELINE configs[3]: {count} independent random SOCPs n={desc['n']} m={desc['m']}, {args.batch_per_gpu} per GPU, "
-                         f"{args.batch_concurrency} host threads per GPU, setup (scs_init) inside the timed region",
-                problems=count, wall_s=wall, problems_per_s=count / wall, admm_iters_per_s=float(np.nansum(tab[:, 2])) / wall,
-                all_solved=bool(np.all(tab[:, 1] == 1)), iters_min_max=[int(np.nanmin(tab[:, 2])), int(np.nanmax(tab[:, 2]))])
+    out = dict(workload=f"BASELINE configs[3]: {count} independent random SOCPs n={desc['n']} m={desc['m']}, {args.batch_per_gpu} per GPU, "
+                        f"{args.batch_concurrency} host threads per GPU, setup (scs_init) inside the timed region",
+               problems=count, wall_s=wall, problems_per_s=count / wall, admm_iters_per_s=float(np.nansum(tab[:, 2])) / wall,
+               all_solved=bool(np.all(tab[:, 1] == 1)), iters_min_max=[int(np.nanmin(tab[:, 2])), int(np.nanmax(tab[:, 2]))])
+    if 0 in kept:  # judged on the host in the manner of test/problem_utils.h:107-249 (scs_amd/verify.py), outside the timed region
+        from scs_amd import verify
+        r, pb = kept[0], probs[0]
+        out["_problem0"] = dict(info=r["info"], verify=verify.verify_solved(pb.sparse(), pb.b, pb.c, pb.cone, r["x"], r["y"], r["s"], r["info"]))
+    return out
 
 
 def secondary_single_gpu(args):
@@ -449,6 +568,34 @@ def secondary_single_gpu(args):
         out["configs2_sdp"] = d
     except Exception as e:
         out["configs2_sdp"] = dict(error=str(e))
+    # ---- the headline problem under the reference's DEFAULT settings: acceleration_lookback = 10 (include/glbopts.h:45),
+    # Anderson acceleration device resident (scs_amd/csrc/aa_dev.hip; call sites src/scs.c:1359-1366, :1439-1447)
+    try:
+        s = HipSolver(args, 0, 0, args.n, 2 * args.n, args.col_nnz, args.seed, 10, 1e-4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.begin()
+        while not s.converged():
+            if s.steps(100) >= s.max_iters:
+                break
+        torch.cuda.synchronize()
+        t_eps = time.perf_counter() - t0
+        st = s.stats()
+        res = s.end()
+        out["headline_aa_on"] = dict(
+            workload=f"the headline problem (random SOCP n={args.n} m={2*args.n} nnz={args.n*args.col_nnz}, same seed) with the reference's "
+                     "default acceleration_lookback=10, acceleration_interval=10, type-I AA; whole solve to eps=1e-4",
+            status=res["status"], iters_to_eps=res["iter"] if res["status_val"] == 1 else None, iters=res["iter"],
+            time_to_eps_s=t_eps if res["status_val"] == 1 else None, solve_wall_s=t_eps, value_it_per_s=res["iter"] / t_eps,
+            accepted_accel_steps=res["accepted_accel_steps"], rejected_accel_steps=res["rejected_accel_steps"],
+            accel_time_s=res["accel_time"] / 1e3, lin_sys_time_s=res["lin_sys_time"] / 1e3, cg_its_total=st["cg_iters"],
+            aa_path="device (aa_dev.hip: l = n + m + 1 >= 32768)" if args.n + 2 * args.n + 1 >= 32768 else "host (aa_host.cpp)",
+            final={k: res[k] for k in ("pobj", "dobj", "res_pri", "res_dual", "gap")},
+            note="every AA step the safeguard rejects (src/aa.c:856-932) costs one wasted iterate; on this family the reference's own "
+                 "safeguard rejects them too (cpu_reference beside this block, tests/test_solve_gpu.py::test_anderson_acceleration_on_matches_reference)")
+        s.close()
+    except Exception as e:
+        out["headline_aa_on"] = dict(error=repr(e))
     # ---- configs[4]: fp32 n=4e6: windowed rate + SpMV bandwidth, then the SAME solve carried to eps = 1e-3
     try:
         n4 = args.fp32_n
@@ -598,6 +745,13 @@ def main():
         dist.broadcast(desc, src=0)
     n, m, col_nnz, seed, K, W, aa = [int(v) for v in desc.tolist()]
 
+    # ---- CPU side leg that needs minutes: the reference to TERMINATION on one configs[3] problem, started first, on its own
+    # NUMA node, so that it is done by the time the GPU work is (collected into batch.parity below)
+    want_cpu = world == 1 and not args.no_cpu_baseline and args.dtype == "f64" and not stub
+    term_child = None
+    if want_cpu and rank == 0 and args.secondary != "none" and args.parity_threads > 0:
+        term_child = _cpu_start(cpu_spec(args, args.batch_n, args.parity_threads, 0, 0, aa=0, side="b", kind="term", seed=1000))
+
     # ---- synthetic problem, one per rank (seed + rank) ----------------------------------------------
     S = StubSolver(rank) if stub else HipSolver(args, rank, local_rank, n, m, col_nnz, seed, aa, eps, args.dtype, args.q_fixed)
     cone = S.cone
@@ -645,27 +799,44 @@ def main():
         recs = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(recs, rec)
 
-    # ---- GPU rate over the CPU baseline's iteration window (rank 0, N = 1) -------------------------
-    gpu_win = gpu_cg_win = gpu_win_state = None
-    want_cpu = world == 1 and not args.no_cpu_baseline and args.dtype == "f64" and not stub
+    # ---- GPU over the CPU baseline's iteration window (rank 0, N = 1), on the CPU leg's OWN tolerance schedule -------------
+    # The CPU legs run with the reference's per-iteration log on, which refreshes the residual norms every iteration and so
+    # tightens the CG tolerances (src/scs.c:1449-1454, :745-762).  Three short re-runs from a fresh scs_init:
+    #   (1) timing on that logged schedule, without host-side logging (scs_amd_set_residuals_every_iter),
+    #   (2) the same iterations with OUR log_csv_filename on: one row per iteration to compare with the reference's rows,
+    #   (3) the unlogged default schedule (what the headline solve runs), for the record.
+    gpu_win = gpu_cg_win = gpu_rows = gpu_win_unlogged = None
     if want_cpu:
-        S.reinit()  # the CPU legs run the problem from a fresh scs_init: so does this window
-        S.begin()
-        S.steps(args.cpu_window_i0)
-        sa = S.stats()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        S.steps(args.cpu_window_iters)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        sb = S.stats()
-        sys.stderr.write("[bench] closing the %d-iteration re-run that mirrors the CPU baseline's window: the library's end-of-solve "
-                         "warnings below (if any) belong to that deliberately unconverged run, not to the headline solve\n"
-                         % (args.cpu_window_i0 + args.cpu_window_iters))
+        import tempfile
+        i0w, kw = args.cpu_window_i0, args.cpu_window_iters
+        sys.stderr.write("[bench] %d-iteration re-runs that mirror the CPU baseline's window: the library's end-of-solve warnings below "
+                         "(if any) belong to those deliberately unconverged runs, not to the headline solve\n" % (i0w + kw))
         sys.stderr.flush()
-        gpu_win_state = S.end()
-        gpu_win = args.cpu_window_iters / dt
-        gpu_cg_win = (sb["cg_iters"] - sa["cg_iters"]) / float(args.cpu_window_iters)
+
+        def window_run():
+            S.begin()
+            S.steps(i0w)
+            sa = S.stats()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            S.steps(kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            sb = S.stats()
+            S.end()
+            return kw / dt, sb["cg_iters"] - sa["cg_iters"]
+
+        S.reinit(resid_every_iter=True)
+        gpu_win, gpu_cg_win = window_run()
+        with tempfile.TemporaryDirectory() as td:
+            S.reinit(log_csv=os.path.join(td, "gpu_log.csv"))
+            S.begin()
+            S.steps(i0w + kw)
+            S.end()
+            names, rows = _read_csv_rows(os.path.join(td, "gpu_log.csv"))
+            gpu_rows = [dict(iter=int(f[names.index("iter")]), **{nm: f[names.index(nm)] for nm in PARITY_COLS}) for f in rows]
+        S.reinit()
+        gpu_win_unlogged, _ = window_run()
     S.close()  # free the headline problem before the side workloads
     cpu1, cpu_early = None, {}
     if want_cpu and rank == 0:  # one core beside the GPU side workloads; the OpenMP legs run afterwards, one at a time (legs that
@@ -754,30 +925,84 @@ def main():
                             "at THIS size (tol 1e-9, <= 1e-7 scale); this run: the reference's default inexact-CG schedule, where "
                             "trajectories legitimately differ by O(tol) -- status / objectives within 1e-3 scale (DESIGN.md section 4)"),
         }
+        aa_child = None
+        if term_child is not None:
+            # collect the reference's to-termination solve (it ran beside the GPU work on its own NUMA node), then give that node
+            # to the AA-on CPU window
+            ref_term = _cpu_collect(term_child, 420.0)
+            if batch_out is not None and "_problem0" in batch_out:
+                ours = batch_out.pop("_problem0")
+                par = dict(problem=f"configs[3] problem 0: random SOCP n={args.batch_n} m={2*args.batch_n} seed=1000, default settings "
+                                   "(inexact-CG schedule), acceleration_lookback=0, eps 1e-4, both sides to termination",
+                           ours={k: ours["info"][k] for k in ("status_val", "status", "iter", "pobj", "dobj", "res_pri", "res_dual", "gap", "scale_updates")},
+                           ours_verify=ours["verify"])
+                if ref_term.get("info"):
+                    ri, oi = ref_term["info"], ours["info"]
+                    scale = max(1.0, abs(ri["pobj"]), abs(ri["dobj"]))
+                    par["reference"] = dict(ri, flavour=ref_term["flavour"], threads=ref_term["threads"], wall_s=ref_term["wall_s"])
+                    par["same_status"] = ri["status_val"] == oi["status_val"]
+                    par["iter_ratio"] = oi["iter"] / max(ri["iter"], 1)
+                    par["iter_diff_is_multiple_of_25"] = (oi["iter"] - ri["iter"]) % 25 == 0
+                    par["pobj_rel_diff"] = abs(oi["pobj"] - ri["pobj"]) / scale
+                    par["dobj_rel_diff"] = abs(oi["dobj"] - ri["dobj"]) / scale
+                    par["ok"] = bool(par["same_status"] and 0.5 <= par["iter_ratio"] <= 2.0 and par["iter_diff_is_multiple_of_25"]
+                                     and par["pobj_rel_diff"] <= 1e-3 and par["dobj_rel_diff"] <= 1e-3 and ours["verify"]["ok"])
+                    par["criteria"] = ("same status_val; iteration counts within 2x and differing by a multiple of CONVERGED_INTERVAL=25 "
+                                       "(src/scs.c:611-649 is evaluated every 25 iterations); pobj / dobj within 1e-3 of max(1, |pobj|, |dobj|); "
+                                       "our (x, y, s) passes the checks of test/problem_utils.h:107-249 recomputed on the host (scs_amd/verify.py)")
+                else:
+                    par["reference"] = dict(error=ref_term.get("error", str(ref_term)))
+                    par["ok"] = None
+                batch_out["parity"] = par
+            if args.secondary == "all" and args.aa_window_threads > 0:
+                aa_child = _cpu_start(cpu_spec(args, n, args.aa_window_threads, 1, args.aa_window_iters, aa=10, side="b"))
         if batch_out is not None:
+            batch_out.pop("_problem0", None)
             out["batch"] = batch_out
         if world == 1 and not stub and args.secondary == "all" and args.dtype == "f64":
             out["secondary"] = secondary_single_gpu(args)
         if want_cpu:
             # the OpenMP legs start while the 1-thread leg is still finishing (one extra core does not disturb them)
             out["cpu_baseline_omp"] = cpu_omp_sweep(args, n, cpu_early, gpu_win)
-            out["cpu_baseline"] = cpu_leg(args, n, 1, cpu1, args.cpu_baseline_timeout, gpu_win, gpu_cg_win, stats2["cg_iters"], res["iter"])
-            ref_state = (out["cpu_baseline"] or {}).pop("state_after_window", None)
-            if ref_state and gpu_win_state and ref_state.get("iter") == gpu_win_state["iter"]:
-                # the SAME problem, the SAME number of ADMM iterations under the reference's default (inexact-CG) schedule on both
-                # sides: how far apart the two trajectories are at the headline size (they differ by O(CG tolerance) per
-                # iteration by construction -- DESIGN.md section 4 -- so this is a closeness figure, not an identity)
-                keys = ("res_pri", "res_dual", "gap", "pobj", "dobj")
-                scale = max(1.0, abs(ref_state["pobj"]), abs(ref_state["dobj"]))
+            out["cpu_baseline"] = cpu_leg(args, n, 1, cpu1, args.cpu_baseline_timeout, gpu_win, stats2["cg_iters"], res["iter"], gpu_cg_win)
+            if out["cpu_baseline"] is not None:
+                out["cpu_baseline"]["gpu_same_window_unlogged_schedule_its_per_s"] = gpu_win_unlogged
+            (out["cpu_baseline"] or {}).pop("state_after_window", None)
+            ref_rows = (out["cpu_baseline"] or {}).pop("log_rows", None)
+            if ref_rows and gpu_rows and len(ref_rows) == len(gpu_rows):
+                # the SAME problem from a fresh scs_init, the SAME iterations, the SAME (logged) tolerance schedule on both sides:
+                # every row of the two per-iteration logs side by side.  Row j = the state after iteration j; the last row = the
+                # returned state.  The linear solves are inexact (tolerances of order 1e0..1e1 on residuals of order 1e2 here), so
+                # the rows differ by O(CG tolerance) -- DESIGN.md section 4 -- this is a closeness figure, not an identity.
+                per_iter, worst = [], 0.0
+                for rr, gg in zip(ref_rows, gpu_rows):
+                    scale = max(1.0, abs(rr["pobj"]), abs(rr["dobj"]))
+                    d = dict(iter=rr["iter"],
+                             res_pri=abs(gg["res_pri"] - rr["res_pri"]) / max(abs(rr["res_pri"]), 1e-300),
+                             res_dual=abs(gg["res_dual"] - rr["res_dual"]) / max(abs(rr["res_dual"]), 1e-300),
+                             gap=abs(gg["gap"] - rr["gap"]) / max(abs(rr["gap"]), scale),
+                             pobj=abs(gg["pobj"] - rr["pobj"]) / scale, dobj=abs(gg["dobj"] - rr["dobj"]) / scale)
+                    if gg["iter"] != rr["iter"]:
+                        d["iter_mismatch"] = [gg["iter"], rr["iter"]]
+                    worst = max(worst, *(d[k] for k in PARITY_COLS))
+                    per_iter.append(d)
                 out["parity_window"] = dict(
-                    iter=ref_state["iter"], gpu={k: gpu_win_state[k] for k in keys}, cpu_reference={k: ref_state[k] for k in keys},
-                    rel_diff=dict(res_pri=abs(gpu_win_state["res_pri"] - ref_state["res_pri"]) / max(abs(ref_state["res_pri"]), 1e-300),
-                                  res_dual=abs(gpu_win_state["res_dual"] - ref_state["res_dual"]) / max(abs(ref_state["res_dual"]), 1e-300),
-                                  pobj=abs(gpu_win_state["pobj"] - ref_state["pobj"]) / scale,
-                                  dobj=abs(gpu_win_state["dobj"] - ref_state["dobj"]) / scale),
-                    note="headline problem, default inexact-CG schedule on both sides, state after the CPU window's last iteration "
-                         "(GPU: scs_amd_solve_end of the capped re-run; reference: last row of its log_csv_filename log); objectives "
-                         "relative to max(1, |pobj|, |dobj|)")
+                    rows=len(ref_rows), schedule="logged on both sides (residual norms refreshed every iteration)",
+                    gpu=gpu_rows, cpu_reference=ref_rows, rel_diff_per_iter=per_iter, rel_diff=per_iter[-1], max_rel_diff=worst,
+                    note="headline problem from a fresh scs_init, default inexact-CG settings with log_csv_filename on BOTH sides (so both "
+                         "refresh the residual norms that set the CG tolerance every iteration); one row per iteration + the final row; "
+                         "res_pri / res_dual relative to the reference's value, gap / objectives relative to max(1, |pobj|, |dobj|)")
+            if aa_child is not None and isinstance(out.get("secondary"), dict) and isinstance(out["secondary"].get("headline_aa_on"), dict):
+                ra = _cpu_collect(aa_child, args.cpu_baseline_timeout + 120.0)
+                ra.pop("log_rows", None)
+                out["secondary"]["headline_aa_on"]["cpu_reference"] = (
+                    dict(its_per_s=ra.get("its_per_s"), window=ra.get("window"), window_s=ra.get("window_s"), threads=ra.get("threads"),
+                         flavour=ra.get("flavour"), accel_s=ra.get("accel_s"), accepted_accel_steps=ra.get("accepted_accel_steps"),
+                         rejected_accel_steps=ra.get("rejected_accel_steps"), cg_its_window=ra.get("cg_its_window"),
+                         state_after_window=ra.get("state_after_window"),
+                         note="reference, acceleration_lookback=10 (its default), same problem, logged schedule; the window spans the first "
+                              "AA solve (iteration 10, src/scs.c:1359-1366) and its safeguard (src/scs.c:1439-1447)")
+                    if ra.get("its_per_s") else dict(error=ra.get("error", str(ra)[:300])))
         else:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())

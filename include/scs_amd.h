@@ -284,6 +284,11 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
 /* test hook: every per-iteration linear solve uses this tolerance instead of the
  * schedule of src/scs.c:745-762 (0 restores the schedule) */
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
+/* measurement hook: recompute the residuals after every ADMM iteration, where the reference does when
+ * `log_csv_filename` is set (src/scs.c:1449-1454).  Those norms feed the next iteration's CG tolerance
+ * (src/scs.c:745-762): a logged reference run follows a tighter schedule than an unlogged one, and this puts
+ * the solve on that schedule without writing a log (bench.py times the CPU window's schedule with it). */
+void scs_amd_set_residuals_every_iter(ScsWork *w, scs_int on);
 /* ---- B1', drop-in form: the reference's internal cone interface -------------------
  * The nine symbols of include/cones.h:80-90 (prefix `_scs_` = glbopts.h's SCS(x)), exported
  * by libscsamd_cones.so so that a reference build links it IN PLACE OF src/cones.o (the

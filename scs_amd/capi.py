@@ -166,6 +166,8 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             lib.scs_amd_solve_end.argtypes = [C.c_void_p, C.POINTER(T.ScsSolution), C.POINTER(T.ScsInfo)]
             lib.scs_amd_set_cg_tol_override.restype = None
             lib.scs_amd_set_cg_tol_override.argtypes = [C.c_void_p, C.c_double]
+            lib.scs_amd_set_residuals_every_iter.restype = None
+            lib.scs_amd_set_residuals_every_iter.argtypes = [C.c_void_p, scs_int]
     lib._scs_types = T
     return lib
 

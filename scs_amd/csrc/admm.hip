@@ -380,6 +380,7 @@ struct SCS_WORK {
   int cur_iter = 0, run_status = SCS_UNFINISHED;
   bool loop_done = false, stepped = false;
   double t_solve0 = 0, t_lin = 0, t_accel = 0, cg_tol_override = 0;
+  bool resid_every_iter = false; // scs_amd_set_residuals_every_iter: the cadence of a logged reference run (src/scs.c:1449-1454)
   // per-iteration CSV log (src/rw.c:686-863): diagnostic, computed on the host
   std::string log_csv_name;
   FILE *log_csv_fout = nullptr;
@@ -1351,6 +1352,7 @@ static int solve_steps(ScsWork *w, int upto) {
     // log after the scale update so that the residual recomputation does not change the
     // algorithm's own cadence more than the reference's does (:1449-1454)
     if (w->log_csv_fout) log_csv_row(w, i);
+    else if (w->resid_every_iter) populate_residuals(w, i);
   }
   return 0;
 }
@@ -1450,6 +1452,15 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info) {
 // test hook: force every per-iteration linear solve to this tolerance (0 = schedule)
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol) {
   if (w) w->cg_tol_override = tol;
+}
+
+// measurement hook: refresh the residuals after EVERY iteration, at the place where the reference does so when
+// `log_csv_filename` is set (src/scs.c:1449-1454).  The refreshed normalised norms feed the CG tolerance of the next
+// iteration (src/scs.c:745-762), so a logged reference run follows a different (tighter) tolerance schedule than an
+// unlogged one; this switch puts our solve on the logged schedule without the host-side CSV work, so that bench.py
+// can time the same schedule the reference's logged CPU window ran.
+void scs_amd_set_residuals_every_iter(ScsWork *w, scs_int on) {
+  if (w) w->resid_every_iter = on != 0;
 }
 
 // test hook: the equilibration of scs_init on caller-owned arrays, host or device

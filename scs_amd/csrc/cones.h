@@ -36,7 +36,8 @@ struct ConeDev {
   int n_psd = 0, psd_kmax = 0, psd_lds_kmax = 0;
   DevBuf<int> psd_off, psd_k;
   BigPsd *psd_big = nullptr; // blocks of order > PSD_LDS_KMAX: chip-wide Jacobi steps
-  DevBuf<real> psd_vprev;   // per block: eigenbasis of the previous projection (warm start; k <= 72)
+  DevBuf<real> psd_vprev;   // per block: eigenbasis of the previous projection (warm start of the LDS kernel, every order it handles)
+  DevBuf<real> psd_tscratch; // per block: T = A Vp of the warm start when three matrices do not fit LDS (orders 73..92)
   long long psd_calls = 0;  // projections since the last cold start
   void reset_warm_start();
   // exponential (primal, dual) and power cones: 3 rows each, after the PSD blocks

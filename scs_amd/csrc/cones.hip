@@ -540,7 +540,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   const int K2m = (kmax + 1) & ~1, ldm = K2m | 1;
   const bool use_lds = k <= lds_kmax; // per block: small blocks stay in LDS next to a large one in the same program
   if (!use_lds) return; // larger blocks: psd_big.h (chip-wide steps)
-  real *A = use_lds ? lds_mat : scratch + (size_t)cone * 2 * K2m * ldm;
+  real *A = lds_mat;
   real *V = A + (size_t)K2 * ld;
   // element (r, c): in LDS row-major with an odd leading dimension (lanes that walk rows hit distinct banks); in the
   // global-memory scratch of large blocks column-major, so the same lanes touch consecutive addresses (the 2x2-block
@@ -557,8 +557,11 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   __syncthreads();
   real *Vg = vprev ? vprev + (size_t)cone * K2m * ldm : nullptr;
   if (Vg && warm) {
-    // V <- Vp;  T <- A Vp;  A <- Vp' T, symmetrised (the rotations assume A == A' exactly)
-    real *Tm = V + (size_t)K2 * ld;
+    // V <- Vp;  T <- A Vp;  A <- Vp' T, symmetrised (the rotations assume A == A' exactly).  T sits behind V in LDS while
+    // three matrices fit (order <= PSD_WARM_KMAX); above that (73..92) it goes through this cone's slice of an HBM scratch --
+    // written and read back by the same workgroup, so it stays in this CU's L1 / the XCD's L2 (round 4: orders 73..92 ran
+    // ~8 cold sweeps per projection before, 64 us per block at order 92 against 3.4 us at order 64)
+    real *Tm = scratch ? scratch + (size_t)cone * K2m * ldm : V + (size_t)K2 * ld;
     for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
       const int i = e / K2, j = e % K2;
       V[i * ld + j] = Vg[i * ld + j];
@@ -909,8 +912,15 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   psd_calls = 0;
   // warm start of the LDS kernel: sized and gated by the largest block that kernel handles (blocks beyond the LDS path
   // carry their own basis in psd_big, and must not switch the small blocks' warm start off)
-  if (n_psd && psd_lds_kmax >= 2 && psd_lds_kmax <= PSD_WARM_KMAX && !getenv("SCS_AMD_PSD_COLD"))
-    psd_vprev.alloc((size_t)n_psd * ((psd_lds_kmax + 1) & ~1) * (((psd_lds_kmax + 1) & ~1) | 1));
+  psd_vprev.release();
+  psd_tscratch.release();
+  int warm_kmax = PSD_LDS_KMAX; // round 4: every order of the LDS kernel is warm started (SCS_AMD_PSD_WARM_KMAX=72 restores round 3's gate)
+  if (const char *e = getenv("SCS_AMD_PSD_WARM_KMAX")) warm_kmax = std::max(0, std::min(PSD_LDS_KMAX, atoi(e)));
+  if (n_psd && psd_lds_kmax >= 2 && psd_lds_kmax <= warm_kmax && !getenv("SCS_AMD_PSD_COLD")) {
+    const size_t per_cone = (size_t)((psd_lds_kmax + 1) & ~1) * (((psd_lds_kmax + 1) & ~1) | 1);
+    psd_vprev.alloc((size_t)n_psd * per_cone);
+    if (psd_lds_kmax > PSD_WARM_KMAX) psd_tscratch.alloc((size_t)n_psd * per_cone); // T = A Vp of the warm start does not fit LDS
+  }
   ep = k->ep;
   ed = k->ed;
   psize = k->psize;
@@ -956,14 +966,14 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
     const int lds_kmax = std::min(psd_kmax, psd_lds_kmax); // largest block order held in LDS
     const int K2l = (lds_kmax + 1) & ~1;
     const bool carry = psd_vprev.p != nullptr;
-    const size_t lds = PSD_LDS_HEADER + (size_t)(carry ? 3 : 2) * K2l * (K2l | 1) * sizeof(real);
+    const size_t lds = PSD_LDS_HEADER + (size_t)(carry && !psd_tscratch.p ? 3 : 2) * K2l * (K2l | 1) * sizeof(real);
     const int warm = carry && (psd_calls % PSD_WARM_RESET) != 0;
     ++psd_calls;
     if (lds > 48 * 1024)
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_psd_jacobi),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
-                       (real *)nullptr, lds_kmax, lds_kmax, status.p, psd_vprev.p, warm);
+                       psd_tscratch.p, lds_kmax, lds_kmax, status.p, psd_vprev.p, warm);
     if (psd_big) psd_big->project(cw, psd_off.p, psd_k.p, status.p, stream);
   }
   proj_exp_pow(cw);

@@ -68,6 +68,9 @@ XP_DEV xreal sq(xreal a) { return a * a; }
 XP_DEV xreal dist2(const Triple &a, const Triple &b) { return sq(a.u - b.u) + sq(a.w - b.w) + sq(a.t - b.t); }
 XP_DEV xreal rho_cap() { return sizeof(xreal) == 8 ? (xreal)700 : (xreal)85; }
 
+#ifdef SCSAMD_EXPPOW_HOST_CHECK
+static long xp_eval_count = 0; // host check build only: evaluations of F spent by live lanes (trip histogram of the root search)
+#endif
 // F(rho) and F'(rho): one exponential, one reciprocal
 XP_DEV void eval_F(const Triple &v, xreal rho, xreal &F, xreal &dF) {
   const xreal e = exp(rho), ei = (xreal)1 / e;
@@ -134,6 +137,9 @@ XP_DEV xreal root_of_F(const Triple &v, bool live) {
       const xreal probe = vmax(vmin(anchor + dir * reach, cap), -cap);
       xreal F, dF;
       eval_F(v, probe, F, dF);
+#ifdef SCSAMD_EXPPOW_HOST_CHECK
+      if (grow) ++xp_eval_count;
+#endif
       const bool beyond = dir > 0 ? !(F < 0) : F < 0; // the probe is past the root: it closes the bracket
       if (grow) {
         if (beyond) {
@@ -164,7 +170,19 @@ XP_DEV xreal root_of_F(const Triple &v, bool live) {
     // the Newton point is taken when it lands strictly inside the bracket and at least halves the previous move
     const bool newton_ok = dF > 0 && xn > nlo && xn < nhi && vabs(xn - x) <= (xreal)0.5 * last;
     const xreal nx = sel(newton_ok, xn, mid);
-    const bool settled = F == 0 || nx == x || nhi - nlo <= ulp * vmax((xreal)1, vabs(x));
+    // converged by Newton's own measure: the step has dropped below the resolution of x.  Without this exit a step that rounds
+    // to x (x is then one end of the still-wide bracket, so `xn > nlo && xn < nhi` fails on the strict test) sent the lane to the
+    // midpoint and it bisected ~50 more trips from there; the loop only leaves when all 64 lanes have settled, so nearly every
+    // wave paid them (eval_F calls per searched triple, 20000 random triples: median 11, p90 56, p99 60 before;
+    // see tests/test_exp_pow_host.py::test_root_search_trip_histogram for the figures after)
+    // (fp32: an eighth of a step of resolution -- with a whole one the fp32 build's worst output error against the fp64 projection
+    // grew from 7e-5 to 5e-4, the reference's fp32 build sits at 2e-4)
+    const xreal tiny = (sizeof(xreal) == 8 ? (xreal)1 : (xreal)0.125) * ulp * vmax((xreal)1, vabs(x));
+    const bool tiny_step = dF > 0 && (xn == x || vabs(F) <= dF * tiny);
+    const bool settled = F == 0 || nx == x || tiny_step || nhi - nlo <= ulp * vmax((xreal)1, vabs(x));
+#ifdef SCSAMD_EXPPOW_HOST_CHECK
+    if (run) ++xp_eval_count;
+#endif
     if (run) {
       lo = nlo;
       hi = nhi;

@@ -30,7 +30,8 @@ struct LinSys {
   bool own_stream = false;
   bool has_P = false;
   bool use_fused = false; // whole solve in one workgroup (small systems)
-  int nt_mode = 0;        // non-temporal policy of the update kernel's streams (SCS_AMD_VEC_NT; 0 = default policy)
+  int nt_mode = 0;        // non-temporal policy of the update kernel's streams (SCS_AMD_VEC_NT; 0 = default policy; bit 2: two chunks per lane in flight)
+  int dir_mode = 0;       // k_cg_direction: bit 0 non-temporal z reads, bit 1 non-temporal p stores, bit 2 two chunks per lane (SCS_AMD_DIR_MODE)
   bool use_cg2 = false;   // two launches per CG iteration (n <= CG2_N_MAX): k_cg2_a + transposed product
 
   CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector

@@ -35,7 +35,7 @@ static inline int vec_grid(long long len) {
   static const int cap = [] {
     const char *e = getenv("SCS_AMD_VEC_MAX_GRID"); // tests shrink it to force grid-striding
     int g = e ? atoi(e) : VEC_MAX_GRID;
-    return (g >= 1 && g <= VEC_MAX_GRID) ? g : VEC_MAX_GRID;
+    return (g >= 1 && g <= PART_CAP / 2) ? g : VEC_MAX_GRID; // z'r and |r| partials share one PART_CAP array (measurement sweeps go to 2048)
   }();
   long long g = (len + SCSAMD_BLOCK - 1) / SCSAMD_BLOCK;
   if (g < 1) g = 1;
@@ -195,7 +195,43 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, re
     stv(r, gtid, R0);
     stv(z, gtid, Z);
   }
-  for (int iv = gtid + gs; iv < nv; iv += gs) { // 16 B per lane per array
+  int iv0 = gtid + gs;
+  if (ntm & 4) { // two 16-byte chunks per lane and array in flight (measurement variant; same per-lane summation order)
+    for (; iv0 + gs < nv; iv0 += 2 * gs) {
+      const int ia = iv0, ib = iv0 + gs;
+      const rvec Pa = ldv_nt(p, ia), Pb = ldv_nt(p, ib), Ga = ldv_nt(Gp, ia), Gb = ldv_nt(Gp, ib), Ma = ldv_nt(M, ia), Mb = ldv_nt(M, ib);
+      rvec Xa = ldv_nt(x, ia), Xb = ldv_nt(x, ib), Ra = ldv_nt(r, ia), Rb = ldv_nt(r, ib), Za, Zb;
+#pragma unroll
+      for (int e = 0; e < RVW; ++e) {
+        Xa.v[e] += alpha * Pa.v[e];
+        const real ri = Ra.v[e] + (-alpha) * Ga.v[e];
+        Ra.v[e] = ri;
+        const real zi = ri * Ma.v[e];
+        Za.v[e] = zi;
+        ztr += zi * ri;
+        const real a = absval(ri);
+        mx = a > mx ? a : mx;
+      }
+#pragma unroll
+      for (int e = 0; e < RVW; ++e) {
+        Xb.v[e] += alpha * Pb.v[e];
+        const real ri = Rb.v[e] + (-alpha) * Gb.v[e];
+        Rb.v[e] = ri;
+        const real zi = ri * Mb.v[e];
+        Zb.v[e] = zi;
+        ztr += zi * ri;
+        const real a = absval(ri);
+        mx = a > mx ? a : mx;
+      }
+      stv_nt(x, ia, Xa);
+      stv_nt(r, ia, Ra);
+      stv(z, ia, Za);
+      stv_nt(x, ib, Xb);
+      stv_nt(r, ib, Rb);
+      stv(z, ib, Zb);
+    }
+  }
+  for (int iv = iv0; iv < nv; iv += gs) { // 16 B per lane per array
     const rvec P = (ntm & 2) ? ldv_nt(p, iv) : ldv(p, iv), G = (ntm & 2) ? ldv_nt(Gp, iv) : ldv(Gp, iv), Mv = ntm ? ldv_nt(M, iv) : ldv(M, iv);
     rvec X = ntm ? ldv_nt(x, iv) : ldv(x, iv), R = ntm ? ldv_nt(r, iv) : ldv(r, iv), Z;
 #pragma unroll
@@ -242,7 +278,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_update(real *x, real *r, re
 __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const real *__restrict__ z, int n,
                                                                const real *part_ztr,
                                                                const real *part_max, int pcount,
-                                                               CgCtl *ctl, int parity) {
+                                                               CgCtl *ctl, int parity, int dmode) {
   __shared__ real red[4];
   // as in k_cg_update: everything this kernel reads is requested up front (one round trip, not four)
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
@@ -273,12 +309,27 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const re
       for (int e = 0; e < RVW; ++e) P0.v[e] = Z0.v[e] + beta * P0.v[e];
       stv(p, gtid, P0);
     }
-    for (int iv = gtid + gs; iv < nv; iv += gs) {
-      const rvec Z = ldv(z, iv);
+    int iv0 = gtid + gs;
+    if (dmode & 4) { // two chunks per lane in flight (measurement variant)
+      for (; iv0 + gs < nv; iv0 += 2 * gs) {
+        const rvec Za = (dmode & 1) ? ldv_nt(z, iv0) : ldv(z, iv0), Zb = (dmode & 1) ? ldv_nt(z, iv0 + gs) : ldv(z, iv0 + gs);
+        rvec Pa = ldv(p, iv0), Pb = ldv(p, iv0 + gs);
+#pragma unroll
+        for (int e = 0; e < RVW; ++e) {
+          Pa.v[e] = Za.v[e] + beta * Pa.v[e];
+          Pb.v[e] = Zb.v[e] + beta * Pb.v[e];
+        }
+        stv(p, iv0, Pa);
+        stv(p, iv0 + gs, Pb);
+      }
+    }
+    for (int iv = iv0; iv < nv; iv += gs) {
+      const rvec Z = (dmode & 1) ? ldv_nt(z, iv) : ldv(z, iv); // z is dead after this read: non-temporal keeps it out of the way (dmode bit 0)
       rvec P = ldv(p, iv);
 #pragma unroll
       for (int e = 0; e < RVW; ++e) P.v[e] = Z.v[e] + beta * P.v[e];
-      stv(p, iv, P);
+      if (dmode & 2) stv_nt(p, iv, P);
+      else stv(p, iv, P);
     }
     for (int i = nv * RVW + gtid; i < n; i += gs) p[i] = z[i] + beta * p[i];
   }
@@ -800,6 +851,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     // streams of the kernel: no better) forces a mode.
     nt_mode = nnzA >= 4000000 ? 1 : 0;
     if (const char *e = getenv("SCS_AMD_VEC_NT")) nt_mode = atoi(e);
+    if (const char *e = getenv("SCS_AMD_DIR_MODE")) dir_mode = atoi(e);
     use_graph = nnzA <= CG_GRAPH_MAX_NNZ;
     if (const char *e = getenv("SCS_AMD_GRAPH")) use_graph = atoi(e) != 0;
     // two launches per CG iteration (k_cg2_a + the transposed product): n small enough for p in LDS, no P
@@ -925,7 +977,7 @@ void LinSys::enqueue_cg_iteration(int q) {
   hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, cg_x, r.p, z.p, p.p, Gp.p, M.p, n,
                      part_pgp, gAt, part_ztr, part_max, c, q, nt_mode);
   hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, part_ztr, part_max,
-                     gv, c, q);
+                     gv, c, q, dir_mode);
 }
 
 // Capture CG_GRAPH_ITERS iterations into an executable graph.  Any failure leaves cg_graph null

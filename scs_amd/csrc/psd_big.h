@@ -487,27 +487,43 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
   const real *Aold = (cur ? B.A1 : B.A) + mat;
   real *Anew = (cur ? B.A : B.A1) + mat;
   real *V = B.V + mat;
-  const int np = sh.nbc / 2, nta = np * np, TR = sh.K64 / BJ_W;
+  // Only the tiles (P, Q) with P <= Q are computed; the mirror tile (Q, P) receives the transpose, so A stays EXACTLY symmetric
+  // from step to step (two independent products Q_P' A[P,Q] Q_Q and Q_Q' A[Q,P] Q_P sum in different orders: symmetric only to
+  // rounding, and k_bj_inner builds its rotations from one triangle) and the step does half the matrix-core work.
+  const int np = sh.nbc / 2, nta = np * (np + 1) / 2, TR = sh.K64 / BJ_W;
   int tile = blockIdx.x;
   if (tile >= nta + np * TR) return;
   const int *flags = Qflag + (size_t)b * npmax;
   const real *Qb = Qbuf + (size_t)b * npmax * BJ_W * BJ_W, *Sb = Sbuf + (size_t)b * npmax * BJ_W * BJ_W;
   if (tile < nta) {
-    const int Pp = tile % np, Qp = tile / np;
+    // tile -> (Pp <= Qp): column Qp of the upper triangle holds Qp + 1 tiles
+    int Qp = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+    while (Qp * (Qp + 1) / 2 > tile) --Qp;
+    while ((Qp + 1) * (Qp + 2) / 2 <= tile) ++Qp;
+    const int Pp = tile - Qp * (Qp + 1) / 2;
     const int2 IJp = bj_pair_sched(Pp, step, sh.nbc, cross), IJq = bj_pair_sched(Qp, step, sh.nbc, cross);
     const int fP = flags[Pp], fQ = flags[Qp];
-    if (Pp == Qp && fP) { // the pair's own tile: the inner sweep's S' (exact zeros, relatively accurate small entries)
-      for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
-        const int i = e & (BJ_W - 1), j = e >> 6;
-        Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = Sb[(size_t)Pp * BJ_W * BJ_W + j * BJ_W + i];
+    if (Pp == Qp) {
+      if (fP) { // the pair's own tile: the inner sweep's S' (exact zeros, relatively accurate small entries)
+        for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
+          const int i = e & (BJ_W - 1), j = e >> 6;
+          Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = Sb[(size_t)Pp * BJ_W * BJ_W + j * BJ_W + i];
+        }
+      } else {
+        for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
+          const int i = e & (BJ_W - 1), j = e >> 6;
+          const size_t g = (size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i);
+          Anew[g] = Aold[g];
+        }
       }
       return;
     }
-    if (!fP && !fQ) { // neither pair rotated: the tile moves to the other copy as it is
+    if (!fP && !fQ) { // neither pair rotated: the tile and its mirror move to the other copy as they are
       for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
         const int i = e & (BJ_W - 1), j = e >> 6;
-        const size_t g = (size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i);
+        const size_t g = (size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i), gm = (size_t)bj_gidx(IJp, j) * ld + bj_gidx(IJq, i);
         Anew[g] = Aold[g];
+        Anew[gm] = Aold[gm];
       }
       return;
     }
@@ -527,7 +543,8 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
     __syncthreads();
     for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
       const int i = e & (BJ_W - 1), j = e >> 6;
-      Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = xs[j * BJ_LD + i];
+      Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = xs[j * BJ_LD + i];                   // A'[P_i, Q_j]
+      Anew[(size_t)bj_gidx(IJp, j) * ld + bj_gidx(IJq, i)] = xs[i * BJ_LD + j];                   // A'[Q_i, P_j] = A'[P_j, Q_i]
     }
     return;
   }
@@ -750,11 +767,12 @@ struct BigPsd {
   long long sweeps_total = 0, projections = 0;
   bool warm_ok = true;
   bool blocked = true;       // tournament over 32-wide block columns with MFMA updates (k_bj_*); false: single columns (k_bp_step)
-  int sweeps_hint = 0;       // sweeps the previous projection needed: that many minus one are enqueued before the first read-back
+  int sweeps_hint[2] = {0, 0}; // sweeps the previous projection of the same kind ([0] cold start, [1] warm start) needed: that many minus one
+                             // are enqueued before the first read-back (a cold projection's ~10 must not size the next warm one's batch)
   bool cross = true;         // blocked: every index pair once per sweep (within pass + cross-pair tournament steps), see bj_pair_sched
   DevBuf<real> Qbuf, Sbuf;   // blocked: per (block, block-column pair) the 64 x 64 factor Q and rotated subproblem S'
   DevBuf<int> Qflag;         // ... and whether the pair's inner sweep rotated at all
-  void reset_warm_start() { calls = 0; have_basis = false; sweeps_hint = 0; }
+  void reset_warm_start() { calls = 0; have_basis = false; sweeps_hint[0] = sweeps_hint[1] = 0; }
 
   // pk: signed orders of all PSD blocks (negative = complex embedding order); blocks above lds_kmax are taken
   void init(const std::vector<int> &pk, int lds_kmax, hipStream_t st) {
@@ -824,12 +842,12 @@ struct BigPsd {
     long long gstep = 0; // launches so far: the copy of A a block is in alternates with the steps IT took (ctl.cur)
     const long long sweeps_before = sweeps_total;
     const int nbc_max = ld / BJ_B, npmax = ld / BJ_W;
-    const int g_upd = npmax * npmax + npmax * (ld / BJ_W); // A tiles + V tiles of the largest block
+    const int g_upd = npmax * (npmax + 1) / 2 + npmax * (ld / BJ_W); // A tiles (P <= Q: the mirror tile is written by the same workgroup) + V tiles of the largest block
     // Sweeps are enqueued in batches: as many as the previous projection of these blocks needed, minus one, before the first
     // read-back, then one at a time (consecutive ADMM iterates need nearly the same count; a block that has converged makes every
     // later launch return at once, as in the PCG loop; the sweep cap of cones.c:1031 is enforced on the device).  One host
     // round trip per sweep cost 50 - 100 us -- a third of a projection of 32 blocks of order 100.
-    int enq = 0, batch = std::max(1, std::min(sweeps_hint - 1, 8)); // (capped: the projection after a cold start needs far fewer)
+    int enq = 0, batch = std::max(1, std::min(sweeps_hint[warm ? 1 : 0] - 1, warm ? 8 : 12));
     while (h_rem[0] > 0 && enq < PSD_MAX_SWEEPS + 4) {
      for (int bsw = 0; bsw < batch; ++bsw, ++enq) {
       if (blocked) {
@@ -852,7 +870,7 @@ struct BigPsd {
       batch = 1;
     }
     sweeps_total += h_rem[1];
-    sweeps_hint = h_rem[1];
+    sweeps_hint[warm ? 1 : 0] = h_rem[1];
     ++projections;
     static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
     if (debug) fprintf(stderr, "[scs_amd psd_big] projection %lld: %s start, sweeps so far %lld (this one %lld)\n", projections, warm ? "warm" : "cold", sweeps_total, sweeps_total - sweeps_before);

@@ -23,3 +23,9 @@ extern "C" void xp_check_project_pow(scs_float *v, scs_float a) {
   const scsamd::Triple r = scsamd::xp::project_pow(t, a, true);
   v[0] = r.u; v[1] = r.w; v[2] = r.t;
 }
+// evaluations of F (one exp each) the root search spent since the last call; resets the counter
+extern "C" long xp_check_take_eval_count(void) {
+  const long c = scsamd::xp::xp_eval_count;
+  scsamd::xp::xp_eval_count = 0;
+  return c;
+}
