@@ -358,6 +358,12 @@ scs_int scs_amd_aa_dev_safeguard(scs_float *f_new, scs_float *x_new, void *a);
 void scs_amd_aa_dev_reset(void *a);
 void scs_amd_aa_dev_finish(void *a);
 void scs_amd_aa_dev_get_stats(const void *a, AaStats *out);
+/* Test hook for the failure convention (src/scs.c:361-371, :1381-1384, include/linsys.h:25-71): the k-th HIP runtime call
+ * the library checks from now on is reported as failed although it succeeded (k <= 0 disarms; SCS_AMD_FAIL_AT=k in the
+ * environment arms it at load).  What must follow: scs_init / scs_init_lin_sys_work return NULL with nothing leaked,
+ * scs_solve returns SCS_FAILED with a NaN-filled solution and the SIGINT handler restored, scs_solve_lin_sys returns
+ * non-zero, and the library stays usable.  Returns the countdown that was armed before the call. */
+long long scs_amd_test_fail_at(long long k);
 /* number of visible HIP devices, or <0 with no usable runtime (never throws) */
 scs_int scs_amd_device_count(void);
 /* select the device used by subsequently created workspaces (default 0) */

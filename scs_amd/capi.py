@@ -147,6 +147,8 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]  # device pointers
         lib.scs_amd_linsys_sync.restype = scs_int
         lib.scs_amd_linsys_sync.argtypes = [C.c_void_p]
+        lib.scs_amd_test_fail_at.restype = C.c_longlong
+        lib.scs_amd_test_fail_at.argtypes = [C.c_longlong]
         lib.scs_amd_device_count.restype = scs_int
         lib.scs_amd_device_count.argtypes = []
         lib.scs_amd_set_device.restype = scs_int

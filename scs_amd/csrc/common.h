@@ -18,6 +18,7 @@
 #include <vector>
 #include <string>
 #include <stdexcept>
+#include <atomic>
 
 #include "../../include/scs_amd.h"
 
@@ -31,7 +32,22 @@ namespace scsamd {
 struct HipError : std::runtime_error {
   explicit HipError(const std::string &m) : std::runtime_error(m) {}
 };
+// Fault injection (tests of the failure convention): every HIP runtime call of this library goes through
+// HIP_CHECK, so ONE countdown covers allocations, copies, synchronisations and the post-launch error polls.  Armed by
+// scs_amd_test_fail_at(k) or the environment (SCS_AMD_FAIL_AT=k, read once): the k-th checked call from then on is
+// reported as hipErrorOutOfMemory although it succeeded; the countdown then disarms itself.  Never armed in normal use
+// (one relaxed atomic load per checked call).
+inline std::atomic<long long> &fail_countdown() {
+  static std::atomic<long long> c{[] {
+    const char *e = getenv("SCS_AMD_FAIL_AT");
+    return e ? atoll(e) : 0LL;
+  }()};
+  return c;
+}
 inline void hip_check(hipError_t e, const char *what, const char *file, int line) {
+  std::atomic<long long> &cd = fail_countdown();
+  if (cd.load(std::memory_order_relaxed) > 0 && cd.fetch_sub(1, std::memory_order_relaxed) == 1 && e == hipSuccess)
+    e = hipErrorOutOfMemory; // injected
   if (e != hipSuccess) {
     char buf[512];
     snprintf(buf, sizeof buf, "scs_amd: HIP error %d (%s) at %s:%d in %s", (int)e,

@@ -1167,6 +1167,9 @@ scs_int scs_amd_set_device(scs_int dev) {
   return 0;
 }
 
+// test hook: arm (k >= 1) or disarm (k <= 0) the fault injection of common.h's hip_check; returns the previous countdown
+long long scs_amd_test_fail_at(long long k) { return fail_countdown().exchange(k > 0 ? k : 0); }
+
 const char *scs_get_lin_sys_method(void) { return "sparse-indirect-pcg-hip-gfx950"; }
 
 ScsLinSysWork *scs_init_lin_sys_work(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r) {

@@ -116,3 +116,50 @@ def test_capped_solve_identities_and_cone_membership_at_full_size(full_problem):
     r2 = capi.solve(lib, prob, verbose=0, acceleration_lookback=0, max_iters=30)
     r3 = capi.solve(lib, prob, verbose=0, acceleration_lookback=0, max_iters=30)
     assert np.array_equal(r2["x"], r3["x"]) and r2["info"]["pobj"] == r3["info"]["pobj"]
+
+
+def test_linear_solve_with_the_admm_loops_zero_cone_weighting_matches_reference_backend():
+    """the full-size comparison above uses a uniform R_y; every real ADMM iteration weights the zero-cone
+    rows 1000x (src/cones.c:349-363: R_y = 1/(1000 scale) there, 1/scale elsewhere), which multiplies the CG iterations.  Same
+    comparison -- one scs_solve_lin_sys through the five-function ABI on both sides, warm start, tol 1e-9, the auto-selected
+    wave-owned-rows kernel -- WITH that weighting (z = 0.1 m, as the benchmark's cone recipe gives) at n = 5e5, m = 1e6,
+    nnz = 5e6, the largest size whose reference leg (OpenMP flavour, a child process with its own libgomp) fits a minute."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from oracle import pyoracle
+    if not pyoracle.ref_available("libscsindir_ref_omp.so"):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    from tests import ref_linsys_child
+    n, m, z = 500000, 1000000, 100000
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "ref.npy")
+        env = dict(os.environ, OMP_NUM_THREADS=str(min(32, os.cpu_count() or 1)), OMP_WAIT_POLICY="passive")
+        child = subprocess.Popen([sys.executable, os.path.join(root, "tests", "ref_linsys_child.py"), str(n), str(m), str(CN), "1234", str(z),
+                                  "1e-9", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        # our side runs while the reference works on the host cores
+        prob, dr, b, s = ref_linsys_child.inputs(n, m, CN, 1234, z)
+        amd = capi.load("libscsamd_linsys.so")
+        T = amd._scs_types
+        w = amd.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
+        assert w
+        xa = b.copy()
+        assert amd.scs_solve_lin_sys(w, xa.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp), 1e-9) == 0
+        st = T.ScsAmdStats()
+        amd.scs_amd_linsys_get_stats(w, C.byref(st))
+        amd.scs_free_lin_sys_work(w)
+        assert st.cg_iters > 300 and st.nnz == n * CN, st.cg_iters  # the weighting makes this a long solve (uniform R_y: ~60)
+        log, _ = child.communicate(timeout=600)
+        assert child.returncode == 0, log[-2000:]
+        xr = np.load(out)
+    scale = np.abs(xr[:n]).max()
+    assert np.abs(xa[:n] - xr[:n]).max() <= 1e-7 * scale, np.abs(xa[:n] - xr[:n]).max() / scale
+    assert np.abs(xa[n:] - xr[n:]).max() <= 1e-7 * max(scale, np.abs(xr[n:]).max())
+    # and the reduced KKT residual of OUR answer, independent of either CG path
+    A = prob.sparse()
+    x, y = xa[:n], xa[n:]
+    r2 = A @ x - dr[n:] * y - b[n:]
+    red = dr[:n] * x + A.T @ y - b[:n] + A.T @ (r2 / dr[n:])
+    assert np.abs(red).max() <= 1e-9 * 1.01 + 1e-10 * np.abs(b).max()

@@ -110,14 +110,52 @@ def test_bench_cpu_baseline_worker_runs_without_a_gpu():
     if not pyoracle.ref_available():
         pytest.skip("oracle/_ref not built")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # spec = kind:threads:n:col_nnz:seed:aa:q_fixed:i0:k
+    # spec = kind:threads:n:col_nnz:seed:aa:q_fixed:i0:k[:numa side]
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-worker", "socp:1:1500:10:1234:0:0:5:10"],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["threads"] == 1 and d["n"] == 1500 and d["iter"] == 15  # ONE capped run of i0 + k iterations
-    assert d["solve_s"] > 0 and d["flavour"] == "libscsindir_ref.so", d
+    # the window legs run through the counting shim (oracle/trace_linsys.c) so that they know the reference's own CG iterations
+    assert d["solve_s"] > 0 and d["flavour"] == "libscsindir_ref_trace.so", d
     # the window [5, 15) is read off the reference's own per-iteration log
     assert d["window"] == [5, 15] and 0 < d["window_s"] < d["solve_s"] and abs(d["its_per_s"] - 10 / d["window_s"]) < 1e-9
+    # one row per iteration + the final row, every parity column; the reference's own CG counts per ADMM iteration
+    assert [r["iter"] for r in d["log_rows"]] == list(range(15)) + [15]
+    assert all(set(r) >= {"res_pri", "res_dual", "gap", "pobj", "dobj"} for r in d["log_rows"])
+    assert len(d["cg_its_by_iter"]) == 15 and d["cg_its_window"] == sum(d["cg_its_by_iter"][5:15]) > 0
+    # the same run WITHOUT the shim gives the same trajectory: the shim only counts (same last row as a plain logged run)
+    from scs_amd import capi, problems
+    import tempfile
+    ref = pyoracle.load_ref("libscsindir_ref.so")
+    pr = problems.random_socp(1500, 3000, 10, seed=1234)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    with tempfile.TemporaryDirectory() as td:
+        log = os.path.join(td, "l.csv")
+        capi.solve(ref, prob, verbose=0, acceleration_lookback=0, max_iters=15, log_csv_filename=log.encode())
+        last = open(log).read().splitlines()[-1].split(",")
+        names = open(log).read().splitlines()[0].split(",")
+    assert float(last[names.index("res_pri")]) == d["log_rows"][-1]["res_pri"]
+    assert float(last[names.index("pobj")]) == d["log_rows"][-1]["pobj"]
+
+
+def test_bench_cpu_termination_worker_and_numa_split():
+    """the to-termination leg behind batch.parity (kind "term") and the NUMA helper: CPU only."""
+    import json
+    import subprocess
+    import sys
+    from oracle import pyoracle
+    if not pyoracle.ref_available("libscsindir_ref_omp.so"):
+        pytest.skip("oracle/_ref not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-worker", "term:2:800:10:1000:0:0:0:0:b"],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["flavour"] == "libscsindir_ref_omp.so" and d["threads"] == 2 and d["info"]["status_val"] == 1
+    assert d["info"]["iter"] % 25 == 0 and d["info"]["iter"] > 0
+    sys.path.insert(0, root)
+    import bench
+    nodes = bench._numa_cpus()
+    assert nodes and all(nodes) and sorted(c for nd in nodes for c in nd) == sorted(set(c for nd in nodes for c in nd))
 
 
 def test_bench_gpus_flag_spawns_that_many_ranks():
