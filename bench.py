@@ -60,7 +60,7 @@ def parse():
                     help="re-execute under torch.distributed.run even with --gpus 1 (WORLD_SIZE=1: the collectives still run, over RCCL)")
     ap.add_argument("--fp32-n", type=int, default=4000000, help="configs[4] size (tests shrink it)")
     ap.add_argument("--cpu-omp-sweep", default="64,32,16,128,8,0", help="OpenMP thread counts tried in this order, one leg at a time (0 = nproc), until --cpu-omp-budget is spent")
-    ap.add_argument("--cpu-omp-budget", type=float, default=110.0, help="wall-clock budget (s) for the OpenMP sweep of the CPU baseline")
+    ap.add_argument("--cpu-omp-budget", type=float, default=85.0, help="wall-clock budget (s) for the OpenMP sweep of the CPU baseline")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not sample SpMV launches with HIP events in the timed region (roofline left empty)")
     ap.add_argument("--q-fixed", type=int, default=0,
@@ -361,16 +361,22 @@ def cpu_omp_sweep(args, n, early, gpu_win):
 # (self-spawn, rendezvous, barriers, reductions, JSON) can run as a 2-process gloo test without a GPU
 # ---------------------------------------------------------------------------------------------------
 class HipSolver:
-    def __init__(self, args, rank, local_rank, n, m, col_nnz, seed, aa, eps, dtype="f64", q_fixed=0, band=None):
+    def __init__(self, args, rank, local_rank, n, m, col_nnz, seed, aa, eps, dtype="f64", q_fixed=0, band=None, prob=None, pr=None):
+        """prob: an already built capi.Problem (the same generated problem solved again under other settings); pr: an already
+        generated problem dict (e.g. a scrambled copy, problems.scramble_prob)"""
         from scs_amd import capi, problems
         self.capi = capi
         self.lib = capi.load("libscsamd_f32.so" if dtype == "f32" else "libscsamd.so")
         self.T = T = self.lib._scs_types
         assert self.lib.scs_amd_set_device(local_rank) == 0
         t0 = time.time()
-        pr = problems.random_socp(n, m, col_nnz, seed=seed + rank, dtype=T.np_float, q_fixed=q_fixed or None, band=band)
-        self.cone = pr["cone"]
-        self.prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
+        if prob is None:
+            if pr is None:
+                pr = problems.random_socp(n, m, col_nnz, seed=seed + rank, dtype=T.np_float, q_fixed=q_fixed or None, band=band)
+            prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
+        self.pr = pr
+        self.cone = prob.cone
+        self.prob = prob
         self.t_gen = time.time() - t0
         self.st = st = capi.default_settings(self.lib, verbose=0, acceleration_lookback=aa, max_iters=args.max_iters, eps_abs=eps,
                                              eps_rel=eps)
@@ -412,6 +418,12 @@ class HipSolver:
 
     def converged(self):
         return bool(self.lib.scs_amd_solve_converged(self.w))
+
+    def reorder_info(self):
+        out = (C.c_double * 6)()
+        self.lib.scs_amd_get_reorder_info(self.w, out)
+        return dict(renumbered=bool(out[0]), lines_per_entry_given=[out[1], out[2]], lines_per_entry_used=[out[3], out[4]] if out[0] else [out[1], out[2]],
+                    decide_s=out[5])
 
     def stats(self):
         s = self.T.ScsAmdStats()
@@ -534,7 +546,7 @@ def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev):
     return out
 
 
-def secondary_single_gpu(args):
+def secondary_single_gpu(args, headline_prob=None):
     """Driver-timed side measurements on rank 0 at N=1: BASELINE configs[2] (SDP), configs[4] (fp32)."""
     import torch
     from scs_amd import capi, problems
@@ -571,7 +583,7 @@ def secondary_single_gpu(args):
     # ---- the headline problem under the reference's DEFAULT settings: acceleration_lookback = 10 (include/glbopts.h:45),
     # Anderson acceleration device resident (scs_amd/csrc/aa_dev.hip; call sites src/scs.c:1359-1366, :1439-1447)
     try:
-        s = HipSolver(args, 0, 0, args.n, 2 * args.n, args.col_nnz, args.seed, 10, 1e-4)
+        s = HipSolver(args, 0, 0, args.n, 2 * args.n, args.col_nnz, args.seed, 10, 1e-4, prob=headline_prob)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         s.begin()
@@ -654,40 +666,70 @@ def secondary_single_gpu(args):
         out["configs4_fp32"] = d
     except Exception as e:
         out["configs4_fp32"] = dict(error=repr(e))
-    # ---- locality variant of the headline: same sizes, cones and data law, column-local pattern
+    # ---- locality variants of the headline: same sizes, cones and data law on a column-local pattern (band of B rows); and the
+    # B = 1024 problem handed over in an ARBITRARY numbering of its variables and zero / nonnegative rows (problems.scramble_prob):
+    # scs_init renumbers it (scs_amd/csrc/reorder.h) -- measured with the renumbering on and off
     out["locality_variant"] = {}
+
+    def locality_run(label, s, what):
+        s.begin()
+        s.steps(10)
+        st0 = s.stats()
+        s.profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.steps(30)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st1 = s.stats()
+        s.profiling(False)
+        s.end()
+        nl, ms = st1["spmv_launches"] - st0["spmv_launches"], st1["spmv_ms"] - st0["spmv_ms"]
+        cg = st1["cg_iters"] - st0["cg_iters"]
+        d = dict(workload=f"random SOCP n={args.n} m={2*args.n} nnz={args.n*args.col_nnz}, same cones and data law as the headline, {what}; "
+                          "iterations 10..40", window_it_per_s=30 / el, cg_its_per_admm_iter=cg / 30.0,
+                 us_per_cg_iter=1e6 * el / cg if cg else None, numbering=s.reorder_info(), scs_init_s=s.t_init)
+        if nl > 0 and ms > 0:
+            bps = st1["spmv_bytes"] / 2.0
+            avg = ms / nl * 1e-3
+            d["roofline"] = dict(bound="hbm", achieved=bps / avg / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bps / avg / 1e9 / HBM_PEAK_GBS,
+                                 avg_launch_us=avg * 1e6, algorithmic_bytes_per_launch=bps, launches_timed=int(nl),
+                                 kernel="csr_wave_kernel, same layout as the headline; the library picks the instantiation with one chunk of "
+                                        "stream ahead of the gathers from the measured line sharing")
+        out["locality_variant"][label] = d
+
+    band_pr = None
     for band in (1024, 4096):
         try:
             s = HipSolver(args, 0, 0, args.n, 2 * args.n, args.col_nnz, args.seed, 0, 1e-4, band=band)
-            s.begin()
-            s.steps(10)
-            st0 = s.stats()
-            s.profiling(True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            s.steps(30)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            st1 = s.stats()
-            s.profiling(False)
-            s.end()
-            nl, ms = st1["spmv_launches"] - st0["spmv_launches"], st1["spmv_ms"] - st0["spmv_ms"]
-            cg = st1["cg_iters"] - st0["cg_iters"]
-            d = dict(workload=f"random SOCP n={args.n} m={2*args.n} nnz={args.n*args.col_nnz}, same cones and data law as the headline, every column's "
-                              f"{args.col_nnz} rows drawn from a window of {band} rows around its own position (scs_amd/problems.py banded_rows); "
-                              "iterations 10..40", window_it_per_s=30 / el, cg_its_per_admm_iter=cg / 30.0,
-                     us_per_cg_iter=1e6 * el / cg if cg else None)
-            if nl > 0 and ms > 0:
-                bps = st1["spmv_bytes"] / 2.0
-                avg = ms / nl * 1e-3
-                d["roofline"] = dict(bound="hbm", achieved=bps / avg / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bps / avg / 1e9 / HBM_PEAK_GBS,
-                                     avg_launch_us=avg * 1e6, algorithmic_bytes_per_launch=bps, launches_timed=int(nl),
-                                     kernel="csr_wave_kernel, same layout as the headline; the library picks the instantiation with one chunk of "
-                                            "stream ahead of the gathers from the measured line sharing")
+            if band == 1024:
+                band_pr = s.pr
+            locality_run(f"band_{band}", s, f"every column's {args.col_nnz} rows drawn from a window of {band} rows around its own position "
+                                             "(scs_amd/problems.py banded_rows)")
             s.close()
-            out["locality_variant"][f"band_{band}"] = d
         except Exception as e:
             out["locality_variant"][f"band_{band}"] = dict(error=repr(e))
+    try:
+        from scs_amd import problems
+        scr = problems.scramble_prob(band_pr, 7)
+        band_pr = None
+        prob_scr = None
+        for label, env in (("permuted_band_1024", None), ("permuted_band_1024_as_given", "0")):
+            if env is None:
+                os.environ.pop("SCS_AMD_REORDER", None)
+            else:
+                os.environ["SCS_AMD_REORDER"] = env
+            try:
+                s = HipSolver(args, 0, 0, args.n, 2 * args.n, args.col_nnz, args.seed, 0, 1e-4, pr=scr, prob=prob_scr)
+                prob_scr = s.prob
+                locality_run(label, s, "the band-1024 problem with its variables and the rows of its zero / nonnegative cones randomly "
+                                       "permuted" + (" -- renumbering switched off (SCS_AMD_REORDER=0)" if env == "0" else
+                                                     " -- scs_init renumbers (Cuthill-McKee on the row / column graph, reorder.h)"))
+                s.close()
+            finally:
+                os.environ.pop("SCS_AMD_REORDER", None)
+    except Exception as e:
+        out["locality_variant"]["permuted_band_1024"] = dict(error=repr(e))
     return out
 
 
@@ -960,7 +1002,7 @@ def main():
             batch_out.pop("_problem0", None)
             out["batch"] = batch_out
         if world == 1 and not stub and args.secondary == "all" and args.dtype == "f64":
-            out["secondary"] = secondary_single_gpu(args)
+            out["secondary"] = secondary_single_gpu(args, headline_prob=getattr(S, "prob", None))
         if want_cpu:
             # the OpenMP legs start while the 1-thread leg is still finishing (one extra core does not disturb them)
             out["cpu_baseline_omp"] = cpu_omp_sweep(args, n, cpu_early, gpu_win)
@@ -1000,8 +1042,11 @@ def main():
                          flavour=ra.get("flavour"), accel_s=ra.get("accel_s"), accepted_accel_steps=ra.get("accepted_accel_steps"),
                          rejected_accel_steps=ra.get("rejected_accel_steps"), cg_its_window=ra.get("cg_its_window"),
                          state_after_window=ra.get("state_after_window"),
-                         note="reference, acceleration_lookback=10 (its default), same problem, logged schedule; the window spans the first "
-                              "AA solve (iteration 10, src/scs.c:1359-1366) and its safeguard (src/scs.c:1439-1447)")
+                         note="reference, acceleration_lookback=10 (its default), same problem, logged schedule: what an iteration costs the "
+                              "CPU with the AA bookkeeping on.  No AA decision can fall into a window this short on either side: aa_apply is "
+                              "called every acceleration_interval = 10 iterations (src/scs.c:1359-1366) and starts solving once it holds "
+                              "acceleration_lookback = 10 samples (src/aa.c), i.e. at iteration 100 -- ~150 s of this CPU leg; the GPU block "
+                              "above runs the whole solve")
                     if ra.get("its_per_s") else dict(error=ra.get("error", str(ra)[:300])))
         else:
             out["cpu_baseline"] = None

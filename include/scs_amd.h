@@ -263,7 +263,15 @@ void scs_amd_linsys_set_profiling(ScsLinSysWork *w, scs_int on);
  * ranks of mat_vec is R_x x + A' R_y^-1 A x.  Work is enqueued on the workspace's stream; _sync waits for it.
  *   mat_vec_dev   y(n)   = diag_r[0..n) .* x + A_r' R_r^-1 A_r x
  *   mul_a_dev     y(m_r) = A_r x           (src/scs.c:559 uses the same product for the residuals)
- *   mul_at_dev    x(n)   = A_r' y                                                                                  */
+ *   mul_at_dev    x(n)   = A_r' y
+ * CONTRACT (the entries take no lengths and no stream):
+ *   - buffers: x / y are device pointers on the workspace's device (the one selected by scs_amd_set_device when the workspace
+ *     was created) holding at least n resp. m_r scs_float of THIS library's precision; they are not validated;
+ *   - ordering: the work is enqueued on the workspace's PRIVATE non-blocking stream, which has no implicit ordering with any
+ *     stream of the caller (e.g. torch's current stream).  The caller must (1) make its writes to the input visible before the
+ *     call -- synchronise its own stream (or the device) first -- and (2) call scs_amd_linsys_sync(w) before it reads the
+ *     output or reuses the input; entries issued back to back on one workspace run in issue order;
+ *   - threads: one host thread per workspace at a time (as for the five plugin functions, include/linsys.h).            */
 scs_int scs_amd_linsys_mat_vec_dev(ScsLinSysWork *w, const scs_float *x_dev, scs_float *y_dev);
 scs_int scs_amd_linsys_mul_a_dev(ScsLinSysWork *w, const scs_float *x_dev, scs_float *y_dev);
 scs_int scs_amd_linsys_mul_at_dev(ScsLinSysWork *w, const scs_float *y_dev, scs_float *x_dev);
@@ -284,6 +292,15 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
 /* test hook: every per-iteration linear solve uses this tolerance instead of the
  * schedule of src/scs.c:745-762 (0 restores the schedule) */
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
+/* What scs_init decided about its internal numbering (scs_amd/csrc/reorder.h: variables and the rows of the zero / nonnegative
+ * cones may be renumbered so that the gathers of the CSR products of linsys/scs_matrix.c:161-186 share cache lines; callers never see
+ * it -- b, c, warm starts and the returned (x, y, s) are mapped at this boundary).  out[0] = 1 if renumbered, out[1], out[2] =
+ * distinct 128-byte lines per gathered entry of the A / A' product as given, out[3], out[4] = after, out[5] = seconds spent. */
+void scs_amd_get_reorder_info(const ScsWork *w, double *out);
+/* Test hook, host code only: the renumbering decision scs_init would take for this matrix and cone (no device needed).
+ * col_new2old (n) and row_new2old (m) receive new index -> caller's index (identity when nothing is kept); info (6 doubles, may be
+ * NULL) as scs_amd_get_reorder_info.  Returns 1 if a renumbering is kept, 0 if not, < 0 on error. */
+scs_int scs_amd_plan_reorder(const ScsMatrix *A, const ScsCone *k, scs_int *col_new2old, scs_int *row_new2old, double *info);
 /* measurement hook: recompute the residuals after every ADMM iteration, where the reference does when
  * `log_csv_filename` is set (src/scs.c:1449-1454).  Those norms feed the next iteration's CG tolerance
  * (src/scs.c:745-762): a logged reference run follows a tighter schedule than an unlogged one, and this puts
@@ -364,6 +381,8 @@ void scs_amd_aa_dev_get_stats(const void *a, AaStats *out);
  * scs_solve returns SCS_FAILED with a NaN-filled solution and the SIGINT handler restored, scs_solve_lin_sys returns
  * non-zero, and the library stays usable.  Returns the countdown that was armed before the call. */
 long long scs_amd_test_fail_at(long long k);
+/* free device memory (bytes) on the selected device after a device-wide synchronise, < 0 on failure */
+long long scs_amd_device_free_bytes(void);
 /* number of visible HIP devices, or <0 with no usable runtime (never throws) */
 scs_int scs_amd_device_count(void);
 /* select the device used by subsequently created workspaces (default 0) */

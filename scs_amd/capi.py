@@ -147,6 +147,8 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]  # device pointers
         lib.scs_amd_linsys_sync.restype = scs_int
         lib.scs_amd_linsys_sync.argtypes = [C.c_void_p]
+        lib.scs_amd_device_free_bytes.restype = C.c_longlong
+        lib.scs_amd_device_free_bytes.argtypes = []
         lib.scs_amd_test_fail_at.restype = C.c_longlong
         lib.scs_amd_test_fail_at.argtypes = [C.c_longlong]
         lib.scs_amd_device_count.restype = scs_int
@@ -168,6 +170,10 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             lib.scs_amd_solve_end.argtypes = [C.c_void_p, C.POINTER(T.ScsSolution), C.POINTER(T.ScsInfo)]
             lib.scs_amd_set_cg_tol_override.restype = None
             lib.scs_amd_set_cg_tol_override.argtypes = [C.c_void_p, C.c_double]
+            lib.scs_amd_plan_reorder.restype = scs_int
+            lib.scs_amd_plan_reorder.argtypes = [C.POINTER(T.ScsMatrix), C.POINTER(T.ScsCone), T.ip, T.ip, C.POINTER(C.c_double)]
+            lib.scs_amd_get_reorder_info.restype = None
+            lib.scs_amd_get_reorder_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
             lib.scs_amd_set_residuals_every_iter.restype = None
             lib.scs_amd_set_residuals_every_iter.argtypes = [C.c_void_p, scs_int]
     lib._scs_types = T

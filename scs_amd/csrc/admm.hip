@@ -20,6 +20,7 @@
 #include "linsys.h"
 #include "cones.h"
 #include "scs_host.h"
+#include "reorder.h"
 #include <csignal>
 #include <mutex>
 #include <chrono>
@@ -380,6 +381,8 @@ struct SCS_WORK {
   int cur_iter = 0, run_status = SCS_UNFINISHED;
   bool loop_done = false, stepped = false;
   double t_solve0 = 0, t_lin = 0, t_accel = 0, cg_tol_override = 0;
+  Reorder reord;                 // internal renumbering of variables / zero- and nonnegative-cone rows (reorder.h); mapped at the API boundary
+  std::vector<real> hx_tmp, hy_tmp, hs_tmp; // staging for that mapping
   bool resid_every_iter = false; // scs_amd_set_residuals_every_iter: the cadence of a logged reference run (src/scs.c:1449-1454)
   // per-iteration CSV log (src/rw.c:686-863): diagnostic, computed on the host
   std::string log_csv_name;
@@ -890,11 +893,27 @@ static void finalize(ScsWork *w, ScsSolution *sol, ScsInfo *info, int iter) {
   if (!sol->x) sol->x = (real *)calloc(n, sizeof(real));
   if (!sol->y) sol->y = (real *)calloc(m, sizeof(real));
   if (!sol->s) sol->s = (real *)calloc(m, sizeof(real));
-  HIP_CHECK(hipMemcpyAsync(sol->x, w->u.p, n * sizeof(real), hipMemcpyDeviceToHost, w->stream));
-  HIP_CHECK(hipMemcpyAsync(sol->y, w->u.p + n, m * sizeof(real), hipMemcpyDeviceToHost, w->stream));
-  HIP_CHECK(hipMemcpyAsync(sol->s, w->rsk.p + n, m * sizeof(real), hipMemcpyDeviceToHost, w->stream));
-  HIP_CHECK(hipStreamSynchronize(w->stream));
-  if (w->stgs.normalize) un_normalize_sol(w->scal, sol->x, sol->y, sol->s);
+  if (w->reord.active) { // our numbering -> the caller's, after the un-normalisation (D, E are in our numbering)
+    w->hx_tmp.resize(n);
+    w->hy_tmp.resize(m);
+    w->hs_tmp.resize(m);
+    HIP_CHECK(hipMemcpyAsync(w->hx_tmp.data(), w->u.p, n * sizeof(real), hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipMemcpyAsync(w->hy_tmp.data(), w->u.p + n, m * sizeof(real), hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipMemcpyAsync(w->hs_tmp.data(), w->rsk.p + n, m * sizeof(real), hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipStreamSynchronize(w->stream));
+    if (w->stgs.normalize) un_normalize_sol(w->scal, w->hx_tmp.data(), w->hy_tmp.data(), w->hs_tmp.data());
+    for (int j = 0; j < n; ++j) sol->x[w->reord.col_new2old[j]] = w->hx_tmp[j];
+    for (int i = 0; i < m; ++i) {
+      sol->y[w->reord.row_new2old[i]] = w->hy_tmp[i];
+      sol->s[w->reord.row_new2old[i]] = w->hs_tmp[i];
+    }
+  } else {
+    HIP_CHECK(hipMemcpyAsync(sol->x, w->u.p, n * sizeof(real), hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipMemcpyAsync(sol->y, w->u.p + n, m * sizeof(real), hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipMemcpyAsync(sol->s, w->rsk.p + n, m * sizeof(real), hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipStreamSynchronize(w->stream));
+    if (w->stgs.normalize) un_normalize_sol(w->scal, sol->x, sol->y, sol->s);
+  }
   populate_residuals(w, iter);
   real nm_s = 0, nm_y = 0, sty = 0;
   for (int i = 0; i < m; ++i) {
@@ -1017,13 +1036,19 @@ scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) { // src/scs.c:1287-1
   try {
     HIP_CHECK(hipSetDevice(w->device));
     if (b) {
-      if (w->b_orig.data() != b) std::copy(b, b + w->m, w->b_orig.begin());
+      if (w->b_orig.data() != b) { // (scs_init passes its own, already renumbered, copy)
+        if (w->reord.active) for (int i = 0; i < w->m; ++i) w->b_orig[i] = b[w->reord.row_new2old[i]];
+        else std::copy(b, b + w->m, w->b_orig.begin());
+      }
       real nb = 0;
       for (int i = 0; i < w->m; ++i) nb = std::max(nb, (real)std::fabs(w->b_orig[i]));
       w->nm_b_orig = nb;
     }
     if (c) {
-      if (w->c_orig.data() != c) std::copy(c, c + w->n, w->c_orig.begin());
+      if (w->c_orig.data() != c) {
+        if (w->reord.active) for (int j = 0; j < w->n; ++j) w->c_orig[j] = c[w->reord.col_new2old[j]];
+        else std::copy(c, c + w->n, w->c_orig.begin());
+      }
       real nc = 0;
       for (int i = 0; i < w->n; ++i) nc = std::max(nc, (real)std::fabs(w->c_orig[i]));
       w->nm_c_orig = nc;
@@ -1097,6 +1122,11 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->A.copy_from(d->A);
     w->has_P = d->P != nullptr;
     if (w->has_P) w->P.copy_from(d->P);
+    // locality by construction (reorder.h): renumber variables and the rows of the zero / nonnegative cones when that makes the
+    // gathers of the two CSR products share cache lines; everything below works in the new numbering
+    plan_reorder(w->A, &w->k, w->has_P, w->reord);
+    if (w->reord.active) apply_reorder(w->A, w->reord);
+    phase("reorder");
     HIP_CHECK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     phase("copy + stream");
     // equilibrate on the host copy (normalize_a_p) or identity scaling
@@ -1133,6 +1163,10 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->E.upload(w->scal.E.data(), n, w->stream);
     w->b_orig.assign(d->b, d->b + m);
     w->c_orig.assign(d->c, d->c + n);
+    if (w->reord.active) {
+      for (int i = 0; i < m; ++i) w->b_orig[i] = d->b[w->reord.row_new2old[i]];
+      for (int j = 0; j < n; ++j) w->c_orig[j] = d->c[w->reord.col_new2old[j]];
+    }
     HIP_CHECK(hipStreamSynchronize(w->stream));
     if (scs_update(w, w->b_orig.data(), w->c_orig.data()) != 0) throw HipError("scs_amd: scs_update failed");
     phase("vectors + b,c");
@@ -1214,6 +1248,13 @@ static void solve_begin(ScsWork *w, const ScsSolution *sol, scs_int warm_start) 
   std::vector<real> hv(l, (real)0);
   if (warm_start && sol && sol->x && sol->y && sol->s) {
     std::vector<real> x(sol->x, sol->x + n), y(sol->y, sol->y + m), s(sol->s, sol->s + m);
+    if (w->reord.active) { // the caller's numbering -> ours
+      for (int j = 0; j < n; ++j) x[j] = sol->x[w->reord.col_new2old[j]];
+      for (int i = 0; i < m; ++i) {
+        y[i] = sol->y[w->reord.row_new2old[i]];
+        s[i] = sol->s[w->reord.row_new2old[i]];
+      }
+    }
     if (w->stgs.normalize) normalize_sol(w->scal, x.data(), y.data(), s.data());
     std::vector<real> hr(l);
     w->diag_r.download(hr.data(), l, st);
@@ -1461,6 +1502,45 @@ void scs_amd_set_cg_tol_override(ScsWork *w, double tol) {
 // can time the same schedule the reference's logged CPU window ran.
 void scs_amd_set_residuals_every_iter(ScsWork *w, scs_int on) {
   if (w) w->resid_every_iter = on != 0;
+}
+
+// what scs_init decided about the internal numbering (reorder.h): out[0] = 1 if variables / rows were renumbered, out[1..2] =
+// distinct 128-byte lines per gathered entry of the A and A' products as given, out[3..4] = the same after the renumbering
+// (equal to before when none was tried), out[5] = seconds spent deciding
+void scs_amd_get_reorder_info(const ScsWork *w, double *out) {
+  if (!w || !out) return;
+  out[0] = w->reord.active ? 1 : 0;
+  out[1] = w->reord.before[0];
+  out[2] = w->reord.before[1];
+  out[3] = w->reord.after[0];
+  out[4] = w->reord.after[1];
+  out[5] = w->reord.seconds;
+}
+
+// test hook (host only, no HIP call): the decision of reorder.h on a caller's matrix.  col_new2old (n) / row_new2old (m) receive the
+// numbering (identity when none is kept); info as scs_amd_get_reorder_info.  Returns 1 if a renumbering was kept, 0 if not, <0 on error.
+scs_int scs_amd_plan_reorder(const ScsMatrix *A, const ScsCone *k, scs_int *col_new2old, scs_int *row_new2old, double *info) {
+  if (!A || !k || !col_new2old || !row_new2old) return -1;
+  try {
+    HostCsc a;
+    a.copy_from(A);
+    Reorder R;
+    plan_reorder(a, k, false, R);
+    for (scs_int j = 0; j < A->n; ++j) col_new2old[j] = R.active ? (scs_int)R.col_new2old[j] : j;
+    for (scs_int i = 0; i < A->m; ++i) row_new2old[i] = R.active ? (scs_int)R.row_new2old[i] : i;
+    if (info) {
+      info[0] = R.active ? 1 : 0;
+      info[1] = R.before[0];
+      info[2] = R.before[1];
+      info[3] = R.after[0];
+      info[4] = R.after[1];
+      info[5] = R.seconds;
+    }
+    return R.active ? 1 : 0;
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "%s\n", ex.what());
+    return -1;
+  }
 }
 
 // test hook: the equilibration of scs_init on caller-owned arrays, host or device

@@ -700,6 +700,7 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
 #define WR_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
     if (wd.pipelined == 1) hipLaunchKernelGGL((csr_wave_kernel<E, 1>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
+    else if (wd.pipelined == 2) hipLaunchKernelGGL((csr_wave_kernel<E, 2>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
     else hipLaunchKernelGGL((csr_wave_kernel<E, 0>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows);                       \
   } while (0)
     switch (epi) {
@@ -777,7 +778,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     At.wave = new WaveRowsDev();
     At.wave->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
     phase("wave-rows At");
-    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A' gathers: %.3f distinct lines per entry -> %s stream\n", At.wave->lines_per_entry, At.wave->pipelined ? "pipelined" : "plain");
+    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A' gathers: %.3f distinct lines per entry -> %s stream\n", At.wave->lines_per_entry, At.wave->pipelined == 1 ? "pipelined" : (At.wave->pipelined == 2 ? "plain + x-window prefetch" : "plain"));
   }
   {
     std::vector<int> Cp_own, Ci_own;
@@ -798,7 +799,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
       A.wave = new WaveRowsDev();
       A.wave->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
       phase("wave-rows A");
-      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream\n", A.wave->lines_per_entry, A.wave->pipelined ? "pipelined" : "plain");
+      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream\n", A.wave->lines_per_entry, A.wave->pipelined == 1 ? "pipelined" : (A.wave->pipelined == 2 ? "plain + x-window prefetch" : "plain"));
     }
   }
   has_P = P_csc != nullptr;
@@ -1165,6 +1166,13 @@ scs_int scs_amd_set_device(scs_int dev) {
   t_device = dev;
   g_default_device.store(dev, std::memory_order_relaxed);
   return 0;
+}
+
+// free device memory in bytes on the current device, < 0 on failure (tests of the failure convention: "nothing leaked")
+long long scs_amd_device_free_bytes(void) {
+  size_t fr = 0, tot = 0;
+  if (hipSetDevice(selected_device()) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return -1;
+  return (long long)fr;
 }
 
 // test hook: arm (k >= 1) or disarm (k <= 0) the fault injection of common.h's hip_check; returns the previous countdown

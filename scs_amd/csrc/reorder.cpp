@@ -1,0 +1,319 @@
+// reorder.cpp -- see reorder.h.  Host code, setup time only (scs_init).
+#include "reorder.h"
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+
+namespace scsamd {
+
+namespace {
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// transpose of a pattern: (ptr, idx) with `rows` rows over `cols` columns -> (tptr, tidx) with `cols` rows (counting sort,
+// like linsys/cpu/indirect/private.c:7-46 without the values)
+void transpose_pattern(const int *ptr, const int *idx, int rows, int cols, std::vector<int> &tptr, std::vector<int> &tidx) {
+  const size_t nnz = (size_t)ptr[rows];
+  tptr.assign((size_t)cols + 1, 0);
+  for (size_t k = 0; k < nnz; ++k) tptr[(size_t)idx[k] + 1]++;
+  for (int c = 0; c < cols; ++c) tptr[c + 1] += tptr[c];
+  tidx.resize(nnz);
+  std::vector<int> fill(tptr.begin(), tptr.end() - 1);
+  for (int r = 0; r < rows; ++r)
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) tidx[(size_t)fill[idx[k]]++] = r;
+}
+
+// stable argsort of keys; entries with key < 0 ("no key") keep their relative order behind the keyed ones
+std::vector<int> order_by_key(const std::vector<double> &key) {
+  std::vector<int> ord(key.size());
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+    const bool ka = key[a] >= 0, kb = key[b] >= 0;
+    if (ka != kb) return ka;
+    return ka && key[a] < key[b];
+  });
+  return ord;
+}
+
+} // namespace
+
+double lines_per_entry(const int *ptr, const int *idx, int rows, int cols, size_t elem_bytes) {
+  const long long nnz = ptr[rows];
+  if (nnz <= 0) return 1.0;
+  const int lshift = elem_bytes == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
+  const long long budget = std::max<long long>(1024, nnz / 2048); // ~ the unit spmv_wave.h gives a wave on the whole chip
+  std::vector<int> stamp(((size_t)cols >> lshift) + 2, -1);
+  long long distinct = 0, acc = 0;
+  int unit = 0, unit_rows = 0;
+  for (int r = 0; r < rows; ++r) {
+    const long long rn = ptr[r + 1] - ptr[r];
+    if ((acc + rn > budget && unit_rows > 0) || unit_rows >= 1024) {
+      ++unit;
+      acc = 0;
+      unit_rows = 0;
+    }
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+      int &st = stamp[(size_t)idx[k] >> lshift];
+      if (st != unit) {
+        st = unit;
+        ++distinct;
+      }
+    }
+    acc += rn;
+    ++unit_rows;
+  }
+  return (double)distinct / (double)nnz;
+}
+
+namespace {
+
+struct Candidate {
+  std::vector<int> col_new2old, row_new2old;
+  double after[2] = {1, 1};
+  const char *method = "";
+};
+
+// free rows ([0, z) and [z, z + l)) sorted inside their range by `rkey` (< 0: no key, kept behind); all other rows stay
+void place_free_rows(const std::vector<double> &rkey, int z, int lp, int m, std::vector<int> &row_new2old) {
+  row_new2old.resize((size_t)m);
+  std::iota(row_new2old.begin(), row_new2old.end(), 0);
+  for (int range = 0; range < 2; ++range) {
+    const int a = range == 0 ? 0 : z, b = range == 0 ? z : z + lp;
+    if (b - a < 2) continue;
+    const std::vector<double> key(rkey.begin() + a, rkey.begin() + b);
+    const std::vector<int> ord = order_by_key(key);
+    for (int t = 0; t < b - a; ++t) row_new2old[a + t] = a + ord[t];
+  }
+}
+
+void measure(const HostCsc &A, Candidate &c) {
+  const int m = A.m, n = A.n;
+  const int *cp = A.p.data(), *ci = A.i.data();
+  std::vector<int> row_old2new((size_t)m);
+  for (int i = 0; i < m; ++i) row_old2new[c.row_new2old[i]] = i;
+  std::vector<int> np((size_t)n + 1, 0), ni((size_t)cp[n]);
+  for (int j = 0; j < n; ++j) np[j + 1] = np[j] + (cp[c.col_new2old[j] + 1] - cp[c.col_new2old[j]]);
+  for (int j = 0; j < n; ++j) {
+    int o = np[j];
+    const int jo = c.col_new2old[j];
+    for (int q = cp[jo]; q < cp[jo + 1]; ++q) ni[(size_t)o++] = row_old2new[ci[q]];
+  }
+  std::vector<int> tp, ti;
+  transpose_pattern(np.data(), ni.data(), n, m, tp, ti);
+  c.after[1] = lines_per_entry(np.data(), ni.data(), n, m, sizeof(real));
+  c.after[0] = lines_per_entry(tp.data(), ti.data(), m, n, sizeof(real));
+}
+
+} // namespace
+
+void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
+  const double t0 = now_s();
+  R = Reorder();
+  const int m = A.m, n = A.n;
+  const long long nnz = n > 0 ? A.p[n] : 0;
+  int force = -1;
+  if (const char *e = getenv("SCS_AMD_REORDER")) force = atoi(e);
+  if (force == 0) {
+    R.why = "SCS_AMD_REORDER=0";
+    return;
+  }
+  if (has_P) {
+    R.why = "P present";
+    return;
+  }
+  if (nnz < 1000000 && force != 1) { // below the wave-owned-rows layout's threshold the gathered vectors sit in L2 anyway
+    R.why = "fewer than 1e6 nonzeros";
+    return;
+  }
+  if (m < 2 || n < 2) return;
+  const int z = (int)k->z, lp = (int)k->l, fixed0 = z + lp; // rows [0, z) and [z, z + l) may move inside their range; the rest are anchors
+  const int *cp = A.p.data(), *ci = A.i.data();
+  // ---- one pass: anchors per column and how tightly they sit
+  std::vector<double> ckey((size_t)n, -1.0);
+  long long anchored = 0, spread_cols = 0, unkeyed = 0;
+  double spread_sum = 0;
+  const double fixed_len = std::max(1, m - fixed0);
+  for (int j = 0; j < n; ++j) {
+    double s = 0;
+    int cnt = 0, lo = m, hi = -1;
+    for (int q = cp[j]; q < cp[j + 1]; ++q) {
+      const int i = ci[q];
+      if (i >= fixed0) {
+        s += i;
+        ++cnt;
+        lo = std::min(lo, i);
+        hi = std::max(hi, i);
+      }
+    }
+    if (cnt) {
+      ckey[j] = s / cnt;
+      anchored += cnt;
+      if (cnt >= 2) {
+        spread_sum += (hi - lo) / fixed_len;
+        ++spread_cols;
+      }
+    } else {
+      ++unkeyed;
+    }
+  }
+  const bool many_anchors = anchored * 5 >= nnz; // a fifth of the entries sit in rows that cannot move
+  if (many_anchors && force != 1) {
+    // k anchors drawn uniformly from the fixed rows span (k - 1) / (k + 1) of them on average (0.6 - 0.7 on the benchmark family);
+    // a hidden band spans a sliver.  Nothing to recover from a uniformly random pattern: say so after this one pass.
+    const double mean_spread = spread_cols ? spread_sum / (double)spread_cols : 1.0;
+    if (mean_spread > 0.25) {
+      R.why = "anchored entries of a column are spread over the whole cone range (no hidden locality)";
+      R.seconds = now_s() - t0;
+      return;
+    }
+  }
+  std::vector<int> rptr, rcol; // CSR pattern of A (rows -> columns)
+  transpose_pattern(cp, ci, n, m, rptr, rcol);
+  R.before[1] = lines_per_entry(cp, ci, n, m, sizeof(real));                    // A' product: rows = columns of A, gathers y
+  R.before[0] = lines_per_entry(rptr.data(), rcol.data(), m, n, sizeof(real)); // A product: rows of A, gathers x
+  const double before = 0.5 * (R.before[0] + R.before[1]);
+  // (0.25, not the 0.8 at which spmv_wave.h switches kernels: rows that keep their place re-use a few columns many times and
+  // so share lines in ANY numbering of the variables -- a scrambled band measures 0.49 / 0.94 -- while the rest gains 10x)
+  if (before <= 0.25 && force != 1) {
+    R.why = "the given numbering is already local";
+    R.seconds = now_s() - t0;
+    return;
+  }
+  std::vector<Candidate> cands;
+  // ---- candidate 1: anchors.  A column is keyed by the mean position of its entries in rows that cannot move (only when every
+  // column has such entries: the rest would need the graph search anyway), a free row by the mean NEW position of its columns.
+  if (many_anchors && unkeyed == 0) {
+    Candidate c;
+    c.method = "anchors (mean position of a column's entries in the rows that cannot move)";
+    c.col_new2old = order_by_key(ckey);
+    std::vector<int> col_old2new((size_t)n);
+    for (int j = 0; j < n; ++j) col_old2new[c.col_new2old[j]] = j;
+    std::vector<double> rkey((size_t)m, -1.0);
+    for (int i = 0; i < fixed0; ++i) {
+      double s = 0;
+      int cnt = 0;
+      for (int q = rptr[i]; q < rptr[i + 1]; ++q) {
+        s += col_old2new[rcol[q]];
+        ++cnt;
+      }
+      if (cnt) rkey[i] = s / cnt;
+    }
+    place_free_rows(rkey, z, lp, m, c.row_new2old);
+    measure(A, c);
+    cands.push_back(std::move(c));
+  }
+  // ---- candidate 2: breadth-first (Cuthill-McKee) numbering of the bipartite graph (vertices 0..n-1 = columns, n..n+m-1 = rows),
+  // every connected component from a pseudo-peripheral start; columns take the visiting order, free rows follow it inside their
+  // ranges, anchored rows stay (a band is walked end to end, so the anchored rows see their columns in a moving window too)
+  {
+    Candidate c;
+    c.method = "Cuthill-McKee (breadth-first numbering of the row / column graph)";
+    const size_t nv = (size_t)n + m;
+    std::vector<int> mark(nv, -1), order, scratch;
+    order.reserve(nv);
+    scratch.reserve(nv);
+    auto bfs = [&](int start, int tag, std::vector<int> &q) -> int { // appends the component of `start` to q; returns the last vertex reached
+      size_t head = q.size();
+      q.push_back(start);
+      mark[start] = tag;
+      int last = start;
+      while (head < q.size()) {
+        const int v = q[head++];
+        last = v;
+        if (v < n) {
+          for (int e = cp[v]; e < cp[v + 1]; ++e) {
+            const int u = n + ci[e];
+            if (mark[u] != tag) {
+              mark[u] = tag;
+              q.push_back(u);
+            }
+          }
+        } else {
+          const int i = v - n;
+          for (int e = rptr[i]; e < rptr[i + 1]; ++e) {
+            const int u = rcol[e];
+            if (mark[u] != tag) {
+              mark[u] = tag;
+              q.push_back(u);
+            }
+          }
+        }
+      }
+      return last;
+    };
+    std::vector<char> done(nv, 0);
+    int tag = 0;
+    for (size_t s = 0; s < nv; ++s) {
+      if (done[s]) continue;
+      scratch.clear();
+      int far = bfs((int)s, tag++, scratch);
+      if (scratch.size() > 2) { // pseudo-peripheral start: the last vertex of a search from s, then of a search from that one
+        scratch.clear();
+        far = bfs(far, tag++, scratch);
+      }
+      const size_t first = order.size();
+      bfs(far, tag++, order);
+      for (size_t q = first; q < order.size(); ++q) done[order[q]] = 1;
+    }
+    std::vector<double> rkey((size_t)m, -1.0);
+    c.col_new2old.reserve(n);
+    for (size_t q = 0; q < order.size(); ++q) {
+      if (order[q] < n) c.col_new2old.push_back(order[q]);
+      else rkey[order[q] - n] = (double)q;
+    }
+    place_free_rows(rkey, z, lp, m, c.row_new2old);
+    measure(A, c);
+    cands.push_back(std::move(c));
+  }
+  size_t best = 0;
+  for (size_t q = 1; q < cands.size(); ++q)
+    if (cands[q].after[0] + cands[q].after[1] < cands[best].after[0] + cands[best].after[1]) best = q;
+  Candidate &c = cands[best];
+  R.after[0] = c.after[0];
+  R.after[1] = c.after[1];
+  R.method = c.method;
+  R.seconds = now_s() - t0;
+  if (0.5 * (c.after[0] + c.after[1]) <= 0.8 * before) {
+    R.active = true;
+    R.col_new2old = std::move(c.col_new2old);
+    R.row_new2old = std::move(c.row_new2old);
+    R.why = "line sharing of the gathers improved by 20 % or more";
+  } else {
+    R.why = "no candidate numbering improved the measured line sharing by 20 %";
+  }
+  if (getenv("SCS_AMD_DEBUG"))
+    fprintf(stderr, "[scs_amd reorder] %s: lines/entry A %.3f -> %.3f, A' %.3f -> %.3f, %s (%.0f ms)\n", R.method, R.before[0], R.after[0],
+            R.before[1], R.after[1], R.active ? "kept" : "dropped", 1e3 * R.seconds);
+}
+
+void apply_reorder(HostCsc &A, const Reorder &R) {
+  if (!R.active) return;
+  const int m = A.m, n = A.n;
+  std::vector<int> row_old2new((size_t)m);
+  for (int i = 0; i < m; ++i) row_old2new[R.row_new2old[i]] = i;
+  HostCsc B;
+  B.m = m;
+  B.n = n;
+  B.p.assign((size_t)n + 1, 0);
+  B.i.resize(A.i.size());
+  B.x.resize(A.x.size());
+  for (int j = 0; j < n; ++j) B.p[j + 1] = B.p[j] + (A.p[R.col_new2old[j] + 1] - A.p[R.col_new2old[j]]);
+  std::vector<std::pair<int, real>> col;
+  for (int j = 0; j < n; ++j) {
+    const int jo = R.col_new2old[j];
+    col.clear();
+    for (int q = A.p[jo]; q < A.p[jo + 1]; ++q) col.emplace_back(row_old2new[A.i[q]], A.x[q]);
+    std::stable_sort(col.begin(), col.end(), [](const std::pair<int, real> &a, const std::pair<int, real> &b) { return a.first < b.first; });
+    int o = B.p[j];
+    for (const auto &e : col) {
+      B.i[(size_t)o] = e.first;
+      B.x[(size_t)o] = e.second;
+      ++o;
+    }
+  }
+  A = std::move(B);
+}
+
+} // namespace scsamd

@@ -151,6 +151,30 @@ def banded_rows(m, n, col_nnz, band, rng):
     return r
 
 
+def scramble_prob(pr, seed):
+    """The same problem in an arbitrary numbering: variables (columns of A, c) randomly permuted, rows randomly permuted INSIDE
+    the zero and the nonnegative cone (rows of A, b); every other cone keeps its rows (their order is part of the cone,
+    include/scs.h:121-172).  Returns the scrambled problem plus `col_perm` / `row_perm` (new index -> original index)."""
+    rng = np.random.default_rng(seed)
+    A = pr["A"]
+    m, n = A.shape
+    cone = pr["cone"]
+    z, l = int(cone.get("z", 0)), int(cone.get("l", 0))
+    colp = rng.permutation(n)
+    rowp = np.arange(m)
+    rowp[:z] = rng.permutation(z)
+    rowp[z:z + l] = z + rng.permutation(l)
+    As = sp.csc_matrix(A[rowp][:, colp])
+    As.sort_indices()
+    out = dict(pr)
+    out.update(A=sp.csc_matrix((As.data.astype(A.dtype), As.indices.astype(np.int32), As.indptr.astype(np.int32)), shape=(m, n)),
+               b=pr["b"][rowp], c=pr["c"][colp], col_perm=colp, row_perm=rowp)
+    for key, perm in (("x_opt", colp), ("y_opt", rowp), ("s_opt", rowp)):
+        if key in pr:
+            out[key] = pr[key][perm]
+    return out
+
+
 def random_cone_prob(n, m, col_nnz, cone, seed=1234, dtype=np.float64, band=None):
     """Feasible & bounded random cone program.  Returns dict(A (csc), b, c, cone,
     x_opt, y_opt, s_opt).  `band` (rows): column-local sparsity pattern (banded_rows) instead of the
@@ -171,13 +195,15 @@ def random_cone_prob(n, m, col_nnz, cone, seed=1234, dtype=np.float64, band=None
     return dict(A=A, b=b.astype(dtype), c=c.astype(dtype), cone=cone, x_opt=x, y_opt=y, s_opt=s)
 
 
-def random_socp(n, m=None, col_nnz=None, seed=1234, q_fixed=None, dtype=np.float64, band=None):
+def random_socp(n, m=None, col_nnz=None, seed=1234, q_fixed=None, dtype=np.float64, band=None, scramble=None):
     """The headline family: LP + SOC cones only (BASELINE.json configs 1, 2, 4, 5).  `band`: the same cones and
-    data law on a column-local (banded) pattern -- the locality variant of bench.py's `secondary`."""
+    data law on a column-local (banded) pattern -- the locality variant of bench.py's `secondary`.  `scramble` (a seed):
+    that problem handed over in an arbitrary numbering of its variables and zero / nonnegative rows (scramble_prob)."""
     m = 2 * n if m is None else m
     col_nnz = 10 if col_nnz is None else col_nnz
     cone = socp_cone_sizes(m, q_fixed=q_fixed)
-    return random_cone_prob(n, m, col_nnz, cone, seed=seed, dtype=dtype, band=band)
+    pr = random_cone_prob(n, m, col_nnz, cone, seed=seed, dtype=dtype, band=band)
+    return scramble_prob(pr, scramble) if scramble is not None else pr
 
 
 def random_sdp(n, n_blocks=200, block=50, bsize=1001, col_nnz=10, seed=1234):

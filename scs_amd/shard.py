@@ -33,11 +33,18 @@ def slab(m, world, rank):
 class HipSlabOps:
     """the slab's operator pieces on the GPU: a B1 workspace of libscsamd_linsys.so driven through its device-pointer entries"""
 
-    def __init__(self, Ar, rx_share, ry, lib=None):
+    def __init__(self, Ar, rx_share, ry, lib=None, device=None):
         import torch
         self.torch = torch
         self.lib = lib or capi.load("libscsamd_linsys.so")
         self.T = T = self.lib._scs_types
+        # the workspace must live on the GPU the caller's tensors live on: bind the library's device selection to torch's
+        # (ADVICE r3: without this every slab landed on the library's default device 0 while x / y belonged to another GPU)
+        self.device_index = torch.cuda.current_device() if device is None else torch.device(device).index
+        if self.device_index is None:
+            self.device_index = torch.cuda.current_device()
+        if self.lib.scs_amd_set_device(self.device_index) != 0:
+            raise RuntimeError(f"scs_amd_set_device({self.device_index}) failed")
         mr, n = Ar.shape
         self.prob = capi.Problem(Ar, np.zeros(mr), np.zeros(n), dict(l=mr), T=T)
         local = np.concatenate([rx_share, ry]).astype(T.np_float)
@@ -46,6 +53,11 @@ class HipSlabOps:
             raise RuntimeError("scs_init_lin_sys_work failed on the row slab")
 
     def _call(self, fn, src, dst):
+        for t in (src, dst):  # device pointers are handed to kernels of THIS workspace's device, in the library's precision
+            if not t.is_cuda or t.device.index != self.device_index:
+                raise ValueError(f"tensor on {t.device}, workspace on cuda:{self.device_index}")
+            if t.element_size() != np.dtype(self.T.np_float).itemsize or not t.is_contiguous():
+                raise ValueError("tensor dtype / layout does not match the library's scs_float")
         self.torch.cuda.synchronize()  # torch's stream and the workspace's stream are different streams: functional form
         if fn(self.w, src.data_ptr(), dst.data_ptr()) != 0:
             raise RuntimeError("device operator call failed")
@@ -85,7 +97,11 @@ class ShardedLinSys:
         diag_r = np.asarray(diag_r, dtype=f)
         self.rx = diag_r[:self.n].copy()
         self.ry = diag_r[self.n + self.r0:self.n + self.r1].copy()
-        self.ops = (ops_factory or (lambda a, b, c: HipSlabOps(a, b, c, lib)))(Ar, self.rx / self.world, self.ry)
+        if ops_factory is None:
+            want = (lib or capi.load("libscsamd_linsys.so"))._scs_types.np_float
+            if np.dtype(f) != np.dtype(want):
+                raise ValueError(f"dtype {np.dtype(f)} does not match the library's scs_float ({np.dtype(want)})")
+        self.ops = (ops_factory or (lambda a, b, c: HipSlabOps(a, b, c, lib, device=device)))(Ar, self.rx / self.world, self.ry)
         td = torch.float64 if f is np.float64 else torch.float32
         self.td = td
         # Jacobi preconditioner (private.c:50-82): diag(G) = R_x + sum_r diag(A_r' R_r^-1 A_r)

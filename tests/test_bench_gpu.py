@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 # measured on the GPU box (profiles/r4_*): largest relative difference over all rows / columns of the two per-iteration logs at
 # the reduced test size, times two ("replace < 0.25 by the measured figure x 2")
-PARITY_WINDOW_MAX = 0.25
+PARITY_WINDOW_MAX = 0.8  # measured 0.399 (gpurun_out r4a: n=6e4, 2-iteration window), x 2; at the headline size: 0.206 over 5 iterations
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -69,7 +69,7 @@ def test_side_workloads_of_the_default_line_at_reduced_sizes():
     residuals, the locality variants) and the OpenMP-sweep plumbing, at sizes that take seconds: every field the driver's
     line carries must be there and sane."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "60000", "--fp32-n", "120000", "--steps", "10", "--warmup", "5",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "120000", "--fp32-n", "120000", "--steps", "10", "--warmup", "5",
                           "--batch-n", "8000", "--batch-per-gpu", "2", "--batch-concurrency", "2", "--cpu-omp-sweep", "4", "--cpu-omp-budget", "120",
                           "--cpu-window-iters", "2", "--parity-threads", "4", "--aa-window-threads", "4"], env=env, capture_output=True, text=True,
                          timeout=900)
@@ -87,6 +87,10 @@ def test_side_workloads_of_the_default_line_at_reduced_sizes():
         assert rec[k] <= 1.5 * rec["limits"][k], (k, rec)
     for band in ("band_1024", "band_4096"):
         assert s["locality_variant"][band]["window_it_per_s"] > 0
+    lv = s["locality_variant"]  # the scrambled band: renumbered inside scs_init (reorder.h) vs solved as given
+    assert lv["permuted_band_1024"]["numbering"]["renumbered"] is True and lv["permuted_band_1024_as_given"]["numbering"]["renumbered"] is False
+    used, given = lv["permuted_band_1024"]["numbering"]["lines_per_entry_used"], lv["permuted_band_1024"]["numbering"]["lines_per_entry_given"]
+    assert sum(used) < 0.5 * sum(given), (used, given)
     assert d["batch"]["all_solved"]
     aa = s["headline_aa_on"]  # the reference's default settings (acceleration_lookback=10) on the headline problem
     assert aa["status"] == "solved" and aa["iters_to_eps"] > 0 and aa["value_it_per_s"] > 0 and aa["accel_time_s"] >= 0
@@ -111,5 +115,6 @@ def test_side_workloads_of_the_default_line_at_reduced_sizes():
         assert 0.5 <= bp["iter_ratio"] <= 2.0 and bp["pobj_rel_diff"] <= 1e-3
         ar = aa["cpu_reference"]
         assert ar["its_per_s"] > 0 and ar["window"] == [1, 22]
-        # AA decisions on this family: the reference's safeguard and ours see the same kind of steps
-        assert ar["accepted_accel_steps"] + ar["rejected_accel_steps"] >= 1
+        # (no AA decision falls into the window: the first solve needs acceleration_lookback = 10 samples, one per call, one call
+        # every acceleration_interval = 10 iterations -> iteration 100, src/aa.c; the GPU side above runs the whole solve)
+        assert ar["accepted_accel_steps"] + ar["rejected_accel_steps"] == 0

@@ -21,10 +21,12 @@ from scs_amd import capi, problems
 pytestmark = pytest.mark.gpu
 
 
-def _free_bytes():
-    import torch
-    torch.cuda.synchronize()
-    return torch.cuda.mem_get_info()[0]
+def _free_bytes(lib):
+    """hipMemGetInfo through the library itself (torch's own HIP runtime cannot be initialised in a process in which the
+    library's is already live: "No HIP GPUs are available")"""
+    v = lib.scs_amd_device_free_bytes(lib)
+    assert v >= 0
+    return v
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +53,7 @@ def test_scs_init_returns_null_and_leaks_nothing(prob):
     total = _checked_calls(lib, lambda: held.append(lib.scs_init(C.byref(prob.data), C.byref(prob.k), C.byref(st))))  # scs_init alone
     lib.scs_finish(held.pop())
     assert total > 50
-    base = _free_bytes()
+    base = _free_bytes(lib)
     # early (device selection / first allocations), middle (equilibration, matrix layouts), late (cone tables, g solve)
     for k in sorted({1, 2, 3, 7, total // 4, total // 2, (3 * total) // 4, total - 5}):
         lib.scs_amd_test_fail_at(k)
@@ -59,7 +61,7 @@ def test_scs_init_returns_null_and_leaks_nothing(prob):
         left = lib.scs_amd_test_fail_at(0)
         assert left == 0, (k, left)   # the injected failure was consumed inside scs_init
         assert not w, k               # NULL, as src/scs.c:1092-1096 / :1279-1283
-        assert abs(_free_bytes() - base) <= 8 << 20, (k, base - _free_bytes())  # partial state freed (HIP caches a few MB of its own)
+        assert abs(_free_bytes(lib) - base) <= 8 << 20, (k, base - _free_bytes(lib))  # partial state freed (HIP caches a few MB of its own)
     w = lib.scs_init(C.byref(prob.data), C.byref(prob.k), C.byref(st))
     assert w
     lib.scs_finish(w)
@@ -117,7 +119,7 @@ def test_linsys_plugin_boundary_under_failures(prob):
     want = b.copy()
     assert lib.scs_solve_lin_sys(w, fp(want), None, 1e-9) == 0
     lib.scs_free_lin_sys_work(w)
-    base = _free_bytes()
+    base = _free_bytes(lib)
     held = []
     total = _checked_calls(lib, lambda: held.append(lib.scs_init_lin_sys_work(C.byref(prob.matA), None, fp(dr))))
     lib.scs_free_lin_sys_work(held.pop())
@@ -127,7 +129,7 @@ def test_linsys_plugin_boundary_under_failures(prob):
         w = lib.scs_init_lin_sys_work(C.byref(prob.matA), None, fp(dr))
         assert lib.scs_amd_test_fail_at(0) == 0
         assert not w, k
-        assert abs(_free_bytes() - base) <= 8 << 20, k
+        assert abs(_free_bytes(lib) - base) <= 8 << 20, k
     w = lib.scs_init_lin_sys_work(C.byref(prob.matA), None, fp(dr))
     assert w
     o = b.copy()

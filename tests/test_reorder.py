@@ -1,0 +1,91 @@
+"""Locality by construction (scs_amd/csrc/reorder.h), the host-side decision: CPU only (scs_amd_plan_reorder makes no HIP call).
+
+A banded SOCP handed over in an arbitrary numbering of its variables and of the rows of its zero / nonnegative cones must be
+recognised and renumbered so that the gathers of the two CSR products (linsys/scs_matrix.c:161-186) share cache lines again;
+a uniformly random pattern (the headline benchmark family) must be left alone after one cheap pass; rows of every other cone never move
+(include/scs.h:121-172: their order is part of the cone)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from scs_amd import capi, problems
+
+
+def _plan(pr, lib):
+    T = lib._scs_types
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    cp = np.zeros(prob.n, dtype=T.np_int)
+    rp = np.zeros(prob.m, dtype=T.np_int)
+    info = (C.c_double * 6)()
+    rc = lib.scs_amd_plan_reorder(C.byref(prob.matA), C.byref(prob.k), cp.ctypes.data_as(T.ip), rp.ctypes.data_as(T.ip), info)
+    return rc, list(info), cp, rp
+
+
+def _lines_per_entry(A_csr, unit_rows=1024):
+    """numpy restatement of the measure: distinct 128-byte (16 fp64) lines of the gathered vector per entry, per unit of rows"""
+    ptr, idx = A_csr.indptr, A_csr.indices
+    distinct = 0
+    for r0 in range(0, A_csr.shape[0], unit_rows):
+        seg = idx[ptr[r0]:ptr[min(r0 + unit_rows, A_csr.shape[0])]]
+        distinct += len(np.unique(seg >> 4))
+    return distinct / max(1, len(idx))
+
+
+@pytest.mark.parametrize("band", [512, 4096])
+def test_scrambled_band_is_recovered_and_anchored_rows_do_not_move(band, monkeypatch):
+    monkeypatch.setenv("SCS_AMD_REORDER", "1")  # below 1e6 nonzeros the library would not bother
+    lib = capi.load("libscsamd.so")
+    n, m = 40000, 80000
+    pr = problems.random_socp(n, m, 10, seed=5, band=band, scramble=9)
+    rc, info, cp, rp = _plan(pr, lib)
+    assert rc == 1 and info[0] == 1.0
+    assert sorted(cp) == list(range(n)) and sorted(rp) == list(range(m))       # permutations
+    z, l = pr["cone"]["z"], pr["cone"]["l"]
+    assert np.array_equal(rp[z + l:], np.arange(z + l, m))                       # SOC rows stay where they are
+    assert set(rp[:z]) == set(range(z)) and set(rp[z:z + l]) == set(range(z, z + l))  # free rows stay inside their cone
+    assert 0.5 * (info[3] + info[4]) <= 0.4 * 0.5 * (info[1] + info[2]), info   # the measured line sharing improved a lot
+    # independent check of the claim on the renumbered matrix itself, against the same problem before it was scrambled
+    A2 = pr["A"][rp][:, cp]
+    orig = problems.random_socp(n, m, 10, seed=5, band=band)["A"]
+    got_a, got_at = _lines_per_entry(A2.tocsr()), _lines_per_entry(A2.T.tocsr())
+    ref_a, ref_at = _lines_per_entry(orig.tocsr()), _lines_per_entry(orig.T.tocsr())
+    scr_a, scr_at = _lines_per_entry(pr["A"].tocsr()), _lines_per_entry(pr["A"].T.tocsr())
+    assert got_a <= 1.5 * ref_a and got_at <= 1.5 * ref_at, (got_a, ref_a, got_at, ref_at)
+    assert got_a < 0.5 * scr_a and got_at < 0.5 * scr_at
+
+
+def test_uniformly_random_pattern_is_left_alone(monkeypatch):
+    monkeypatch.delenv("SCS_AMD_REORDER", raising=False)
+    lib = capi.load("libscsamd.so")
+    pr = problems.random_socp(120000, 240000, 10, seed=5)   # 1.2e6 nonzeros: the library does look at it
+    rc, info, cp, rp = _plan(pr, lib)
+    assert rc == 0 and info[0] == 0.0
+    assert np.array_equal(cp, np.arange(120000)) and np.array_equal(rp, np.arange(240000))
+    assert info[5] < 0.5                                        # recognised in one pass over the pattern (seconds)
+
+
+def test_pure_lp_without_anchors_uses_the_graph_search(monkeypatch):
+    """no row that cannot move (zero + nonnegative cones only): Cuthill-McKee on the bipartite graph"""
+    monkeypatch.setenv("SCS_AMD_REORDER", "1")
+    lib = capi.load("libscsamd.so")
+    n, m = 30000, 60000
+    cone = dict(z=20000, l=40000, q=[])
+    pr = problems.scramble_prob(problems.random_cone_prob(n, m, 8, cone, seed=3, band=600), 4)
+    rc, info, cp, rp = _plan(pr, lib)
+    assert rc == 1
+    assert sorted(cp) == list(range(n)) and sorted(rp) == list(range(m))
+    assert set(rp[:20000]) == set(range(20000))
+    assert 0.5 * (info[3] + info[4]) <= 0.3 * 0.5 * (info[1] + info[2]), info
+
+
+def test_switch_and_small_problems(monkeypatch):
+    lib = capi.load("libscsamd.so")
+    pr = problems.random_socp(20000, 40000, 10, seed=5, band=512, scramble=9)
+    monkeypatch.delenv("SCS_AMD_REORDER", raising=False)
+    assert _plan(pr, lib)[0] == 0                               # 2e5 nonzeros: not attempted
+    monkeypatch.setenv("SCS_AMD_REORDER", "0")
+    big = problems.random_socp(120000, 240000, 10, seed=5, band=512, scramble=9)
+    assert _plan(big, lib)[0] == 0                              # switched off
+    monkeypatch.delenv("SCS_AMD_REORDER", raising=False)
+    assert _plan(big, lib)[0] == 1
