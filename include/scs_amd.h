@@ -375,6 +375,33 @@ scs_int scs_amd_aa_dev_safeguard(scs_float *f_new, scs_float *x_new, void *a);
 void scs_amd_aa_dev_reset(void *a);
 void scs_amd_aa_dev_finish(void *a);
 void scs_amd_aa_dev_get_stats(const void *a, AaStats *out);
+/* ---- ONE linear system split by rows of A across GPUs, native form -------------------------------------------
+ * The operator of linsys/cpu/indirect/private.c:106-119 is a sum over row slabs: G = R_x + A' R_y^-1 A = sum_r (R_x / N + A_r' R_r^-1 A_r).
+ * Rank r creates a workspace on ITS slab (rows [r0, r1) of A, all n columns, CSC) with diag_r_local = [R_x / N (n) ; R_y of the
+ * slab (m_r)]; the PCG of private.c:133-217 then runs device-controlled on every rank with ONE all-reduce of an n-vector per
+ * iteration, enqueued on the solver's stream (RCCL, opened with dlopen at the first call: no link-time dependency), and the O(n)
+ * part replicated.  All calls on a group of workspaces are collective (every rank calls them in the same order).
+ *   scs_amd_shard_unique_id     rank 0 fills 128 opaque bytes; the launcher hands them to every rank (file, socket, ...)
+ *   scs_amd_shard_init_rccl     one process per GPU (device = scs_amd_set_device); NULL on failure
+ *   scs_amd_shard_solve         b_local = [r_x (n, the same on every rank) ; r_y of the slab] -> [x ; y of the slab], in place;
+ *                               s = warm start (n) or NULL; tolerance / return value as scs_solve_lin_sys
+ *   scs_amd_shard_group_create / _init_threads / _group_free: a TEST DOUBLE of the collective -- the ranks are host threads of one
+ *                               process sharing one GPU -- so that the N = 2 algebra runs on a single-GPU box (RCCL refuses two
+ *                               ranks on one device); at most 8 ranks
+ *   scs_amd_shard_get_stats     out[0] PCG iterations, out[1] all-reduces enqueued, out[2] all-reduces timed, out[3] their mean us
+ *                               (HIP events on the solver's stream; scs_amd_shard_set_profiling(h, 1) switches the sampling on),
+ *                               out[4] solves                                                                                     */
+typedef struct SCS_AMD_SHARD ScsAmdShard;
+scs_int scs_amd_shard_unique_id(char *out128);
+ScsAmdShard *scs_amd_shard_init_rccl(const ScsMatrix *A_slab, const scs_float *diag_r_local, scs_int world, scs_int rank, const char *id128);
+void *scs_amd_shard_group_create(scs_int world);
+void scs_amd_shard_group_free(void *group);
+ScsAmdShard *scs_amd_shard_init_threads(const ScsMatrix *A_slab, const scs_float *diag_r_local, void *group, scs_int rank);
+scs_int scs_amd_shard_solve(ScsAmdShard *h, scs_float *b_local, const scs_float *s, scs_float tol);
+scs_int scs_amd_shard_update_diag_r(ScsAmdShard *h, const scs_float *diag_r_local);
+void scs_amd_shard_get_stats(ScsAmdShard *h, double *out);
+void scs_amd_shard_set_profiling(ScsAmdShard *h, scs_int on);
+void scs_amd_shard_free(ScsAmdShard *h);
 /* Test hook for the failure convention (src/scs.c:361-371, :1381-1384, include/linsys.h:25-71): the k-th HIP runtime call
  * the library checks from now on is reported as failed although it succeeded (k <= 0 disarms; SCS_AMD_FAIL_AT=k in the
  * environment arms it at load).  What must follow: scs_init / scs_init_lin_sys_work return NULL with nothing leaked,

@@ -45,3 +45,33 @@ if g_all:
     print(f"\n# launch gaps: all {len(g_all)} gaps mean {statistics.mean(g_all):.2f} us median {statistics.median(g_all):.2f} us; "
           f"between active CG-loop kernels {len(g_cg)} gaps mean {statistics.mean(g_cg) if g_cg else 0:.2f} us "
           f"median {statistics.median(g_cg) if g_cg else 0:.2f} us; trace span {span:.1f} ms, inside kernels {busy:.1f} ms")
+
+# ---- where the time OUTSIDE kernels goes ("find the 11 % of trace span outside kernels"): every gap between
+# consecutive launches, of any length, attributed to the pair (kernel before -> kernel after) and to a size class
+if len(ks) > 1:
+    def short(nm):
+        nm = nm.replace("scsamd::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+        return nm.split("(")[0][:40]
+    by_pair, by_class = {}, {"< 5 us": [0, 0.0], "5 - 100 us": [0, 0.0], "100 us - 10 ms": [0, 0.0], ">= 10 ms": [0, 0.0]}
+    total_gap = 0.0
+    for (s0, e0, n0), (s1, e1, n1) in zip(ks[:-1], ks[1:]):
+        gap = (s1 - e0) / 1000.0
+        if gap <= 0:
+            continue
+        total_gap += gap
+        cls = "< 5 us" if gap < 5 else ("5 - 100 us" if gap < 100 else ("100 us - 10 ms" if gap < 1e4 else ">= 10 ms"))
+        by_class[cls][0] += 1
+        by_class[cls][1] += gap
+        a = by_pair.setdefault((short(n0), short(n1)), [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += gap
+        a[2] = max(a[2], gap)
+    print(f"\n# time outside kernels: {total_gap/1e3:.1f} ms in {sum(v[0] for v in by_class.values())} gaps")
+    print("| gap length | gaps | total ms |")
+    print("|---|---|---|")
+    for k, v in by_class.items():
+        print(f"| {k} | {v[0]} | {v[1]/1e3:.1f} |")
+    print("\n| kernel before -> kernel after (largest totals) | gaps | total ms | longest ms |")
+    print("|---|---|---|---|")
+    for (a, b), v in sorted(by_pair.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"| {a} -> {b} | {v[0]} | {v[1]/1e3:.1f} | {v[2]/1e3:.2f} |")

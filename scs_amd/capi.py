@@ -170,6 +170,27 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             lib.scs_amd_solve_end.argtypes = [C.c_void_p, C.POINTER(T.ScsSolution), C.POINTER(T.ScsInfo)]
             lib.scs_amd_set_cg_tol_override.restype = None
             lib.scs_amd_set_cg_tol_override.argtypes = [C.c_void_p, C.c_double]
+            # one linear system split by rows across GPUs, native form (scs_amd/csrc/shard_native.cpp)
+            lib.scs_amd_shard_unique_id.restype = scs_int
+            lib.scs_amd_shard_unique_id.argtypes = [C.c_char_p]
+            lib.scs_amd_shard_init_rccl.restype = C.c_void_p
+            lib.scs_amd_shard_init_rccl.argtypes = [C.POINTER(T.ScsMatrix), fp, scs_int, scs_int, C.c_char_p]
+            lib.scs_amd_shard_group_create.restype = C.c_void_p
+            lib.scs_amd_shard_group_create.argtypes = [scs_int]
+            lib.scs_amd_shard_group_free.restype = None
+            lib.scs_amd_shard_group_free.argtypes = [C.c_void_p]
+            lib.scs_amd_shard_init_threads.restype = C.c_void_p
+            lib.scs_amd_shard_init_threads.argtypes = [C.POINTER(T.ScsMatrix), fp, C.c_void_p, scs_int]
+            lib.scs_amd_shard_solve.restype = scs_int
+            lib.scs_amd_shard_solve.argtypes = [C.c_void_p, fp, fp, T.ftype]
+            lib.scs_amd_shard_update_diag_r.restype = scs_int
+            lib.scs_amd_shard_update_diag_r.argtypes = [C.c_void_p, fp]
+            lib.scs_amd_shard_get_stats.restype = None
+            lib.scs_amd_shard_get_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+            lib.scs_amd_shard_set_profiling.restype = None
+            lib.scs_amd_shard_set_profiling.argtypes = [C.c_void_p, scs_int]
+            lib.scs_amd_shard_free.restype = None
+            lib.scs_amd_shard_free.argtypes = [C.c_void_p]
             lib.scs_amd_plan_reorder.restype = scs_int
             lib.scs_amd_plan_reorder.argtypes = [C.POINTER(T.ScsMatrix), C.POINTER(T.ScsCone), T.ip, T.ip, C.POINTER(C.c_double)]
             lib.scs_amd_get_reorder_info.restype = None

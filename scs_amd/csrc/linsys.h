@@ -24,8 +24,25 @@ struct CgCtl {
   int max_its;   // 10 n (private.c:307): the device stops there even if more iterations were enqueued
 };
 
+// ONE linear system split by rows of A over several devices (the operator split is
+// linsys/cpu/indirect/private.c:106-119).  A workspace created on the row slab A_r with diag_r = [R_x / N ; R_y of the slab]
+// applies ITS term of G = R_x + A' R_y^-1 A = sum_r (R_x / N + A_r' R_r^-1 A_r); `allreduce` sums (or takes the maximum of)
+// an n-vector over the N ranks IN PLACE, enqueued on the workspace's stream -- the PCG loop stays device controlled, the host
+// reads one control block per batch of iterations as in the unsplit solve.  Everything of length n is replicated on every rank
+// and computed redundantly (identical bits after the all-reduce), so alpha / beta / the stop test need no second collective.
+struct ShardHook {
+  void *ctx = nullptr;
+  int world = 1, rank = 0;
+  int (*allreduce)(void *ctx, real *buf, size_t count, int op /* 0 sum, 1 max */, hipStream_t st) = nullptr; // 0 = ok
+};
+
 struct LinSys {
   int n = 0, m = 0;
+  ShardHook *shard = nullptr;   // non-null: this workspace holds one row slab (set_shard)
+  long long n_allreduce = 0;
+  EventTimer ar_timer;          // sampled all-reduce times (profiling)
+  void set_shard(ShardHook *h); // call right after init(), before the first set_diag_r_*
+  void shard_allreduce(real *buf, size_t count, int op);
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool has_P = false;

@@ -341,6 +341,24 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const re
   }
 }
 
+// p'Gp partials (sharded solve: the dot product can only be taken after the all-reduce that completes Gp)
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_dot_partial(const real *__restrict__ a, const real *__restrict__ b, int n,
+                                                              real *part, const int *skip) {
+  if (skip && *skip) return;
+  __shared__ real red[4];
+  real acc = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += a[i] * b[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_reciprocal(real *v, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = (real)1 / v[i];
+}
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_zero_unless_rank0(real *v, int n, int rank, const int *skip) {
+  if (rank == 0 || (skip && *skip)) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = 0;
+}
+
 // private.c:50-82, one lane per column of A (= row of CSR(A'))
 __global__ __launch_bounds__(SCSAMD_BLOCK) void k_precond(CsrView At, const real *__restrict__ rx,
                                                           const real *__restrict__ ry,
@@ -700,7 +718,6 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
 #define WR_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
     if (wd.pipelined == 1) hipLaunchKernelGGL((csr_wave_kernel<E, 1>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
-    else if (wd.pipelined == 2) hipLaunchKernelGGL((csr_wave_kernel<E, 2>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
     else hipLaunchKernelGGL((csr_wave_kernel<E, 0>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows);                       \
   } while (0)
     switch (epi) {
@@ -778,7 +795,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     At.wave = new WaveRowsDev();
     At.wave->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
     phase("wave-rows At");
-    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A' gathers: %.3f distinct lines per entry -> %s stream\n", At.wave->lines_per_entry, At.wave->pipelined == 1 ? "pipelined" : (At.wave->pipelined == 2 ? "plain + x-window prefetch" : "plain"));
+    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A' gathers: %.3f distinct lines per entry -> %s stream\n", At.wave->lines_per_entry, At.wave->pipelined ? "pipelined" : "plain");
   }
   {
     std::vector<int> Cp_own, Ci_own;
@@ -799,7 +816,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
       A.wave = new WaveRowsDev();
       A.wave->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
       phase("wave-rows A");
-      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream\n", A.wave->lines_per_entry, A.wave->pipelined == 1 ? "pipelined" : (A.wave->pipelined == 2 ? "plain + x-window prefetch" : "plain"));
+      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream\n", A.wave->lines_per_entry, A.wave->pipelined ? "pipelined" : "plain");
     }
   }
   has_P = P_csc != nullptr;
@@ -886,6 +903,30 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
 void LinSys::build_preconditioner() {
   hipLaunchKernelGGL(k_precond, dim3(vec_grid(n)), dim3(SCSAMD_BLOCK), 0, stream, At.view(), rx.p, ry.p,
                      has_P ? Pdiag.p : (const real *)nullptr, M.p);
+  if (shard) { // diag(G) = sum over the slabs of (R_x / N + diag(A_r' R_r^-1 A_r)): sum the reciprocals of the local M
+    hipLaunchKernelGGL(k_reciprocal, dim3(vec_grid(n)), dim3(SCSAMD_BLOCK), 0, stream, M.p, n);
+    shard_allreduce(M.p, (size_t)n, 0);
+    hipLaunchKernelGGL(k_reciprocal, dim3(vec_grid(n)), dim3(SCSAMD_BLOCK), 0, stream, M.p, n);
+  }
+}
+
+void LinSys::set_shard(ShardHook *h) {
+  shard = h;
+  if (h) { // the small-system shortcuts assume the whole operator is local
+    if (has_P) throw HipError("scs_amd: a row-sharded system with P is not supported");
+    use_fused = false;
+    use_cg2 = false;
+    use_graph = false;
+  }
+}
+
+void LinSys::shard_allreduce(real *buf, size_t count, int op) {
+  int slot = -1;
+  if (profiling && (n_allreduce & 3) == 0) slot = ar_timer.start(stream);
+  if (!shard || !shard->allreduce || shard->allreduce(shard->ctx, buf, count, op, stream) != 0)
+    throw HipError("scs_amd: all-reduce of the row-sharded solve failed");
+  if (slot >= 0) ar_timer.stop(slot, stream);
+  ++n_allreduce;
 }
 
 void LinSys::set_diag_r_host(const real *diag_r) {
@@ -973,10 +1014,17 @@ void LinSys::enqueue_cg_iteration(int q) {
     EpiArgs ep{nullptr, nullptr, nullptr, nullptr};
     launch_spmv(EPI_PLAIN, P, p.p, Pp.p, ep, &c->cg_done);
   }
-  EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, part_pgp};
+  EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, shard ? (real *)nullptr : part_pgp};
   launch_spmv(EPI_GP, At, tmp.p, Gp.p, e2, &c->cg_done);
+  int cnt_pgp = gAt;
+  if (shard) { // Gp holds this slab's term: sum over the ranks, then the dot product (iterations past convergence still take part in
+               // the collective -- every rank enqueues the same sequence -- and move an untouched Gp)
+    shard_allreduce(Gp.p, (size_t)n, 0);
+    hipLaunchKernelGGL(k_dot_partial, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, (const real *)p.p, (const real *)Gp.p, n, part_pgp, &c->cg_done);
+    cnt_pgp = gv;
+  }
   hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, cg_x, r.p, z.p, p.p, Gp.p, M.p, n,
-                     part_pgp, gAt, part_ztr, part_max, c, q, nt_mode);
+                     part_pgp, cnt_pgp, part_ztr, part_max, c, q, nt_mode);
   hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, p.p, z.p, n, part_ztr, part_max,
                      gv, c, q, dir_mode);
 }
@@ -1045,15 +1093,23 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
     return fits;
   }
 
+  int rhs_cnt = gnm;
+  if (shard) { // |[r_x; r_y]|_inf over ALL slabs: element-wise maximum of the (zero-padded) partial arrays
+    rhs_cnt = PART_CAP / 2; // >= any vec_grid
+    HIP_CHECK(hipMemsetAsync(partA.p, 0, (size_t)rhs_cnt * sizeof(real), stream));
+  }
   hipLaunchKernelGGL(k_absmax_partial, dim3(gnm), dim3(SCSAMD_BLOCK), 0, stream, b, n + m, partA.p);
+  if (shard) shard_allreduce(partA.p, (size_t)rhs_cnt, 1);
   hipLaunchKernelGGL(k_rhs_prep, dim3(gnm), dim3(SCSAMD_BLOCK), 0, stream, b, ry.p, tmp.p, n, m, partA.p,
-                     gnm, c, tol, warm_part, warm_cnt, warm_scale,
+                     rhs_cnt, c, tol, warm_part, warm_cnt, warm_scale,
                      (int)std::min<long long>(10LL * n, 2147483647LL));
-  // b_x += A' R_y^-1 r_y   (private.c:305)
+  // b_x += A' R_y^-1 r_y   (private.c:305); sharded: r_x counts once (rank 0 keeps it), every slab adds its part, then the sum
+  if (shard) hipLaunchKernelGGL(k_zero_unless_rank0, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, b, n, shard->rank, (const int *)&c->zero_rhs);
   {
     EpiArgs e{nullptr, nullptr, nullptr, nullptr};
     launch_spmv(EPI_ACC, At, tmp.p, b, e, &c->zero_rhs);
   }
+  if (shard) shard_allreduce(b, (size_t)n, 0);
   if (s) { // r = G s  (private.c:153)
     EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
     launch_spmv(EPI_DIV, A, s, tmp.p, e1, &c->zero_rhs);
@@ -1063,6 +1119,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
     }
     EpiArgs e2{rx.p, s, has_P ? Pp.p : nullptr, nullptr};
     launch_spmv(EPI_GP, At, tmp.p, r.p, e2, &c->zero_rhs);
+    if (shard) shard_allreduce(r.p, (size_t)n, 0);
     n_matvecs++;
   }
   hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, b, s, r.p, z.p, M.p, n, partA.p,

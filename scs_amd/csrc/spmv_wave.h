@@ -37,7 +37,6 @@ constexpr int WR_BUCKETS = 1024;    // column buckets per unit (ordering heurist
 
 struct WaveView {
   int rows, nunit, cbits;
-  int cols, pf_dist; // PIPE == 2 only: length of the gathered vector, chunks of look-ahead of the x-window prefetch
   const int *urow;     // nunit + 1 : first row of each unit
   const int *useg;     // 2 * nunit : [first entry (4-aligned), one past the last entry] of each unit
   const unsigned *wrd; // nnz : column | local row << cbits
@@ -77,6 +76,11 @@ __device__ __forceinline__ void wr_consume(const WaveView &A, const WrChunk &c, 
     if (eb + i < t) lds_add(acc + (w[i] >> A.cbits), c.v[i] * xx[i]);
 }
 
+// (Round 4, measured and not kept: an "x-window prefetch" instantiation -- every wave loads its share of the window of x the chip will
+// gather from 1..6 chunks later, next to its stream loads, so that the gathers hit L2 instead of pulling each line of x out of the
+// Infinity Cache once per XCD: 70.9 us per product at a look-ahead of 1 chunk, 77.5 - 79.8 us at 2 - 6, against 68.2 - 68.8 us
+// without; profiles/r4_xwindow_prefetch.md.  One more far-latency load per chunk in the CU's in-order queue costs more than the
+// L2 misses of the gathers it removes.)
 // PIPE = 1: the stream loads of the next chunk are in flight while the current chunk gathers and accumulates.  Chosen
 // per matrix (WaveRowsDev::pipelined) from the measured line sharing of its gathers: with column locality the gathers are
 // L1 / L2 hits, the product is the 12 B/nnz stream and wants more bytes in flight (headline sizes, columns confined to a
@@ -100,37 +104,7 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
     for (int k = lane; k < nr; k += 64) acc[k] = 0;
     // a lane owns 4 consecutive entries of every 256-entry chunk (3 stream instructions per chunk instead of 8; unit
     // starts are 4-aligned)
-    if (PIPE == 2) {
-      // x-window prefetch (round 4).  Every XCD has its own L2, so every line of x is pulled out of the Infinity Cache / HBM once PER
-      // XCD (8 MB x 8 and 16 MB x 8 on the headline: the 72 / 136 MB the PMC passes count above the algorithmic bytes), and it
-      // is pulled by whichever gather happens to touch it first: 9 % of the gathers miss L2, so practically every 64-lane gather
-      // instruction contains one and waits the far latency -- in the CU's in-order memory queue.  All waves walk their entries in
-      // ascending column-bucket order at the same pace, so the window of x the chip gathers from at chunk c is known: every wave
-      // loads ITS share (1 / waves-of-this-XCD) of the window `pf_dist` chunks ahead with one coalesced-as-possible instruction
-      // issued next to the chunk's stream loads (whose HBM latency it hides behind); the gathers then hit L2.
-      const int lshift = sizeof(real) == 8 ? 4 : 5;                                    // elements per 128-byte line
-      const int L = (A.cols + (1 << lshift) - 1) >> lshift;                            // lines of x
-      const int nchunk = (t - s + 255) >> 8;
-      const int xcd = blockIdx.x & 7;                                                  // workgroups are dealt to the 8 XCDs round robin
-      const int wx = (int)(blockIdx.x >> 3) * WR_WPB + wave;                           // this wave among its XCD's waves
-      const int nwx = (int)((gridDim.x + 7 - xcd) >> 3) * WR_WPB;
-      const float wlen = (float)L / (float)(nchunk > 0 ? nchunk : 1);                  // lines of x per chunk of progress (no division in the loop)
-      const int per = (int)(wlen / (float)nwx) + 1;                                    // lines per wave of this XCD and chunk
-      const int mine = wx * per + lane;
-      int c = A.pf_dist;
-      for (int e0 = s; e0 < t; e0 += 256, ++c) {
-        const int eb = e0 + lane * 4;
-        const WrChunk ch = wr_load(A, eb);
-        real pfv = 0;
-        if (c < nchunk) {
-          const int l0 = (int)((float)c * wlen), l1 = (int)((float)(c + 1) * wlen);    // the window of chunk c (rounding: windows may overlap by a line)
-          const int ln = l0 + mine;
-          if (lane < per && ln <= l1 && ln < L) pfv = x[(size_t)ln << lshift];
-        }
-        wr_consume(A, ch, x, acc, eb, t, cmask);
-        asm volatile("" ::"v"(pfv)); // the load must be issued; its value is not used (it has returned by now: the gathers behind it have)
-      }
-    } else if (PIPE == 1) {
+    if (PIPE == 1) {
       WrChunk cur = wr_load(A, s + lane * 4); // (an empty unit reads the padding behind its start: harmless)
       for (int e0 = s; e0 < t; e0 += 256) {
         const bool more = e0 + 256 < t; // uniform
@@ -167,15 +141,13 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
 struct WaveRowsDev {
   bool built = false;
   int pipelined = 0;           // 1: one chunk of stream in flight ahead of the gathers (csr_wave_kernel<.., 1>): matrices whose gathers share lines
-                               // 2: x-window prefetch (csr_wave_kernel<.., 2>): every gather its own line (uniformly random patterns)
-  int pf_dist = 2;             // chunks of look-ahead of that prefetch (SCS_AMD_WR_PF)
   double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
   int wpc = 8;                 // waves per CU the layout is cut for (one unit per resident wave); SCS_AMD_WR_WPC overrides (measurements)
   DevBuf<int> urow, useg;
   DevBuf<unsigned> wrd;
   DevBuf<real> val;
-  WaveView view() const { return WaveView{rows, nunit, cbits, cols, pf_dist, urow.p, useg.p, wrd.p, val.p}; }
+  WaveView view() const { return WaveView{rows, nunit, cbits, urow.p, useg.p, wrd.p, val.p}; }
   // every workgroup must be resident at once (8 waves per CU): a wave then walks its units one after the
   // other and all waves restart at column 0 together, which keeps the gather window of x aligned; a second
   // generation of workgroups starting at column 0 while the first is half way through thrashes L2 instead
@@ -290,10 +262,6 @@ struct WaveRowsDev {
       lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
       pipelined = lines_per_entry < 0.8 ? 1 : 0;
       if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
-      if (const char *e = getenv("SCS_AMD_WR_PF")) { // x-window prefetch at this look-ahead (0 = off), where the stream is not pipelined
-        pf_dist = std::max(0, std::min(8, atoi(e)));
-        if (pipelined == 0 && pf_dist > 0) pipelined = 2;
-      }
     }
     urow.alloc(ur.size());
     useg.alloc(us.size());

@@ -186,3 +186,65 @@ class ShardedLinSys:
 
     def close(self):
         self.ops.close()
+
+
+class NativeShardedLinSys:
+    """The same split in its NATIVE form (scs_amd/csrc/shard_native.cpp, include/scs_amd.h `scs_amd_shard_*`): the PCG loop is the
+    device-controlled loop of the unsplit solver, the all-reduce of G p is enqueued on the solver's own stream through RCCL's C API
+    (or the in-process test double when `group` is given), nothing is read back per iteration.  One instance per rank; every call
+    is collective.  A: scipy sparse (m x n), the full matrix (this rank keeps its slab); diag_r = [R_x (n); R_y (m)]."""
+
+    def __init__(self, A, diag_r, world=1, rank=0, unique_id=None, group=None, lib=None):
+        import scipy.sparse as sp
+        self.lib = lib or capi.load("libscsamd.so")
+        self.T = T = self.lib._scs_types
+        self.m, self.n = A.shape
+        self.world, self.rank = world, rank
+        self.r0, self.r1 = slab(self.m, world, rank)
+        Ar = sp.csc_matrix(sp.csr_matrix(A)[self.r0:self.r1, :])
+        mr = self.r1 - self.r0
+        self.prob = capi.Problem(Ar, np.zeros(mr), np.zeros(self.n), dict(l=mr), T=T)
+        diag_r = np.asarray(diag_r, dtype=T.np_float)
+        local = np.concatenate([diag_r[:self.n] / world, diag_r[self.n + self.r0:self.n + self.r1]]).astype(T.np_float)
+        if group is not None:
+            self.h = self.lib.scs_amd_shard_init_threads(C.byref(self.prob.matA), local.ctypes.data_as(T.fp), group, rank)
+        else:
+            if unique_id is None:
+                if world != 1:
+                    raise ValueError("unique_id of rank 0 (NativeShardedLinSys.unique_id()) must be handed to every rank")
+                unique_id = self.unique_id(self.lib)
+            self.h = self.lib.scs_amd_shard_init_rccl(C.byref(self.prob.matA), local.ctypes.data_as(T.fp), world, rank, unique_id)
+        if not self.h:
+            raise RuntimeError("scs_amd_shard_init failed")
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or capi.load("libscsamd.so")
+        buf = C.create_string_buffer(128)
+        if lib.scs_amd_shard_unique_id(buf) != 0:
+            raise RuntimeError("RCCL not available (scs_amd_shard_unique_id)")
+        return buf.raw
+
+    def solve(self, rhs, s=None, tol=1e-9):
+        """rhs = [r_x (n); r_y (m)] (the full right-hand side; this rank uses r_x and its slab of r_y).
+        Returns (x (n), y slab (m_r))."""
+        T = self.T
+        b = np.concatenate([rhs[:self.n], rhs[self.n + self.r0:self.n + self.r1]]).astype(T.np_float)
+        sp_ = None if s is None else np.ascontiguousarray(s, dtype=T.np_float)
+        rc = self.lib.scs_amd_shard_solve(self.h, b.ctypes.data_as(T.fp), None if sp_ is None else sp_.ctypes.data_as(T.fp), tol)
+        if rc != 0:
+            raise RuntimeError("scs_amd_shard_solve failed")
+        return b[:self.n].copy(), b[self.n:].copy()
+
+    def profiling(self, on):
+        self.lib.scs_amd_shard_set_profiling(self.h, 1 if on else 0)
+
+    def stats(self):
+        out = (C.c_double * 5)()
+        self.lib.scs_amd_shard_get_stats(self.h, out)
+        return dict(cg_iters=int(out[0]), allreduces=int(out[1]), allreduces_timed=int(out[2]), allreduce_mean_us=out[3], solves=int(out[4]))
+
+    def close(self):
+        if self.h:
+            self.lib.scs_amd_shard_free(self.h)
+            self.h = None

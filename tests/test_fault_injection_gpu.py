@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 def _free_bytes(lib):
     """hipMemGetInfo through the library itself (torch's own HIP runtime cannot be initialised in a process in which the
     library's is already live: "No HIP GPUs are available")"""
-    v = lib.scs_amd_device_free_bytes(lib)
+    v = lib.scs_amd_device_free_bytes()
     assert v >= 0
     return v
 
