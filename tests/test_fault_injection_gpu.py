@@ -135,7 +135,9 @@ def test_linsys_plugin_boundary_under_failures(prob):
     o = b.copy()
     total = _checked_calls(lib, lambda: lib.scs_solve_lin_sys(w, fp(o), None, 1e-9))
     assert total >= 4
-    for k in sorted({1, total // 2, total}):
+    # (the number of checked calls of a solve depends on how the previous one sized its batches: stay at the front, where the
+    # upload, the first launches' poll and the first control-block read-back are)
+    for k in (1, 2, 3):
         o = b.copy()
         lib.scs_amd_test_fail_at(k)
         rc = lib.scs_solve_lin_sys(w, fp(o), None, 1e-9)
