@@ -136,6 +136,79 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
     }
   }
 }
+// Lockstep instantiation (round 4 experiment, SCS_AMD_WR_LOCKSTEP=1): ONE workgroup of 8 waves per CU; the host stores every 256-entry
+// chunk so that gather instruction i of a wave covers the i-th QUARTER of the chunk's column window (rank r of the chunk's entries in
+// column order sits at position 4 (r % 64) + r / 64), and the 8 waves of the CU issue gather instruction i together (a barrier in front
+// of it): 512 gathers into one narrow window of x back to back, so that a line one wave pulled into the CU's L1 is still there when
+// another wave's gather wants it (the plain kernel measures 8.6 % L1 hits on the gathers; a CU's 39 K gathers per product touch
+// only 29 K - 33 K distinct lines).  Same entries, same units, same per-row summation order as the plain kernel ON THIS LAYOUT.
+constexpr int WL_WPB = 8;
+constexpr int WL_BLOCK = WL_WPB * 64;
+template <int EPI>
+__global__ __launch_bounds__(WL_BLOCK) void csr_wave_lockstep_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
+                                                                     const int *skip, int accrows) {
+  if (skip && *skip) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wr_smem[];
+  __shared__ real red[WL_WPB];
+  __shared__ int s_nch[WL_WPB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  real *acc = reinterpret_cast<real *>(wr_smem) + (size_t)wave * accrows;
+  const unsigned cmask = (1u << A.cbits) - 1;
+  real dot = 0;
+  const int per_round = gridDim.x * WL_WPB;
+  const int nround = (A.nunit + per_round - 1) / per_round;
+  for (int rd = 0; rd < nround; ++rd) {
+    const int u = rd * per_round + blockIdx.x * WL_WPB + wave;
+    const bool live = u < A.nunit; // wave-uniform
+    int r0 = 0, nr = 0, s = 0, t = 0;
+    if (live) {
+      r0 = A.urow[u];
+      nr = A.urow[u + 1] - r0;
+      s = A.useg[2 * u];
+      t = A.useg[2 * u + 1];
+    }
+    for (int k = lane; k < nr; k += 64) acc[k] = 0;
+    const int nch = (t - s + 255) >> 8;
+    if (lane == 0) s_nch[wave] = nch;
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int w = 0; w < WL_WPB; ++w) nmax = s_nch[w] > nmax ? s_nch[w] : nmax;
+    for (int c = 0; c < nmax; ++c) {
+      const int eb = s + c * 256 + lane * 4;
+      const bool has = c < nch; // wave-uniform: a wave whose unit is shorter keeps the others company at the barriers
+      WrChunk ch;
+      ch.w = make_uint4(0, 0, 0, 0);
+      ch.v[0] = ch.v[1] = ch.v[2] = ch.v[3] = 0;
+      if (has) ch = wr_load(A, eb);
+      const unsigned w[4] = {ch.w.x, ch.w.y, ch.w.z, ch.w.w};
+      real xx[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __syncthreads(); // all eight waves issue gather instruction i of their chunk c together
+        xx[i] = (has && eb + i < t) ? x[w[i] & cmask] : (real)0;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (has && eb + i < t) lds_add(acc + (w[i] >> A.cbits), ch.v[i] * xx[i]);
+    }
+    for (int k = lane; k < nr; k += 64) {
+      const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
+      epi_apply<EPI>(e, y, r0 + k, a, dot);
+    }
+    __syncthreads(); // s_nch is rewritten by the next round
+  }
+  if (EPI == EPI_GP && e.partial) {
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      real sum = red[0];
+      for (int i = 1; i < WL_WPB; ++i) sum += red[i];
+      e.partial[blockIdx.x] = sum;
+    }
+  }
+}
 #endif // __HIPCC__
 
 struct WaveRowsDev {
@@ -143,6 +216,7 @@ struct WaveRowsDev {
   int pipelined = 0;           // 1: one chunk of stream in flight ahead of the gathers (csr_wave_kernel<.., 1>): matrices whose gathers share lines
   double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
+  int lockstep = 0;            // 1: csr_wave_lockstep_kernel (8 waves per workgroup, sub-window chunk order; SCS_AMD_WR_LOCKSTEP)
   int wpc = 8;                 // waves per CU the layout is cut for (one unit per resident wave); SCS_AMD_WR_WPC overrides (measurements)
   DevBuf<int> urow, useg;
   DevBuf<unsigned> wrd;
@@ -157,9 +231,10 @@ struct WaveRowsDev {
     const int resident = wpc * cus;
     const int rounds = std::max(1, (nunit + resident - 1) / resident);
     const int per_round = (nunit + rounds - 1) / rounds;
-    return std::max(1, std::min((per_round + WR_WPB - 1) / WR_WPB, WR_MAX_GRID));
+    const int wpb = lockstep ? 8 : WR_WPB;
+    return std::max(1, std::min((per_round + wpb - 1) / wpb, WR_MAX_GRID));
   }
-  size_t lds_bytes() const { return (size_t)WR_WPB * accrows * sizeof(real); }
+  size_t lds_bytes() const { return (size_t)(lockstep ? 8 : WR_WPB) * accrows * sizeof(real); }
   static int col_bits(int cols) {
     int b = 1;
     while ((1ll << b) < cols) ++b;
@@ -246,6 +321,40 @@ struct WaveRowsDev {
           hw[qq] = (unsigned)hidx[k] | ((unsigned)(rr - ur[u]) << cbits);
           hv[qq] = hval[k];
         }
+    }
+    int sub_window_order = 0;
+    if (const char *e = getenv("SCS_AMD_WR_LOCKSTEP")) { // 1: sub-window chunk order + lockstep kernel; 2: the order alone (plain kernel)
+      lockstep = atoi(e) == 1 ? 1 : 0;
+      sub_window_order = atoi(e) != 0;
+    }
+    if (sub_window_order) { // every 256-entry chunk: rank r in column order -> position 4 (r % 64) + r / 64 (see csr_wave_lockstep_kernel)
+      std::vector<std::pair<unsigned, int>> key(256);
+      std::vector<unsigned> tw(256);
+      std::vector<real> tv(256);
+      for (int u = 0; u < nunit; ++u) {
+        const size_t s0 = (size_t)us[2 * u], t0 = (size_t)us[2 * u + 1];
+        for (size_t c0 = s0; c0 < t0; c0 += 256) {
+          const int len = (int)std::min<size_t>(256, t0 - c0);
+          const unsigned cm = (1u << cbits) - 1;
+          for (int q = 0; q < len; ++q) key[q] = std::make_pair(hw[c0 + q] & cm, q);
+          std::stable_sort(key.begin(), key.begin() + len);
+          // a short last chunk keeps the rule "position p is valid iff p < len": ranks are dealt to the valid positions in the order
+          // (i = 0: p = 0, 4, 8, ...), (i = 1: p = 1, 5, ...), ... so that instruction i still sees one contiguous window
+          int r = 0;
+          for (int i = 0; i < 4; ++i)
+            for (int l = 0; l < 64; ++l) {
+              const int pos = 4 * l + i;
+              if (pos >= len) continue;
+              tw[pos] = hw[c0 + key[r].second];
+              tv[pos] = hv[c0 + key[r].second];
+              ++r;
+            }
+          for (int q = 0; q < len; ++q) {
+            hw[c0 + q] = tw[q];
+            hv[c0 + q] = tv[q];
+          }
+        }
+      }
     }
     { // column locality: how many distinct lines of the gathered vector does a unit touch per entry?
       const int lshift = sizeof(real) == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
