@@ -718,12 +718,14 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
 #define WR_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
     if (wd.lockstep) {                                                                                                 \
-      static bool attr_set = false; /* eight waves' accumulators can pass the 64 KB a kernel gets without asking */     \
+      static bool attr_set = false; /* many waves' accumulators can pass the 64 KB a kernel gets without asking */     \
       if (!attr_set) {                                                                                                 \
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csr_wave_lockstep_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csr_wave_lockstep_kernel<E, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csr_wave_lockstep_kernel<E, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); \
         attr_set = true;                                                                                               \
       }                                                                                                                \
-      hipLaunchKernelGGL((csr_wave_lockstep_kernel<E>), dim3(g), dim3(WL_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
+      if (wd.ls_wpb == 16) hipLaunchKernelGGL((csr_wave_lockstep_kernel<E, 16>), dim3(g), dim3(1024), lds, stream, v, x, y, e, skip, wd.accrows, wd.ls_bmode); \
+      else hipLaunchKernelGGL((csr_wave_lockstep_kernel<E, 8>), dim3(g), dim3(512), lds, stream, v, x, y, e, skip, wd.accrows, wd.ls_bmode); \
     } else if (wd.pipelined == 1) hipLaunchKernelGGL((csr_wave_kernel<E, 1>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
     else hipLaunchKernelGGL((csr_wave_kernel<E, 0>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows);                       \
   } while (0)

@@ -142,11 +142,9 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
 // of it): 512 gathers into one narrow window of x back to back, so that a line one wave pulled into the CU's L1 is still there when
 // another wave's gather wants it (the plain kernel measures 8.6 % L1 hits on the gathers; a CU's 39 K gathers per product touch
 // only 29 K - 33 K distinct lines).  Same entries, same units, same per-row summation order as the plain kernel ON THIS LAYOUT.
-constexpr int WL_WPB = 8;
-constexpr int WL_BLOCK = WL_WPB * 64;
-template <int EPI>
-__global__ __launch_bounds__(WL_BLOCK) void csr_wave_lockstep_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
-                                                                     const int *skip, int accrows) {
+template <int EPI, int WL_WPB>
+__global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
+                                                                        const int *skip, int accrows, int bmode) {
   if (skip && *skip) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char wr_smem[];
   __shared__ real red[WL_WPB];
@@ -185,7 +183,8 @@ __global__ __launch_bounds__(WL_BLOCK) void csr_wave_lockstep_kernel(WaveView A,
       real xx[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        __syncthreads(); // all eight waves issue gather instruction i of their chunk c together
+        if (bmode == 4 || (bmode == 2 && (i & 1) == 0) || (bmode == 1 && i == 0))
+          __syncthreads(); // all waves of the CU issue gather instruction i of their chunk c together (bmode: barriers per chunk)
         xx[i] = (has && eb + i < t) ? x[w[i] & cmask] : (real)0;
       }
 #pragma unroll
@@ -216,7 +215,8 @@ struct WaveRowsDev {
   int pipelined = 0;           // 1: one chunk of stream in flight ahead of the gathers (csr_wave_kernel<.., 1>): matrices whose gathers share lines
   double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
-  int lockstep = 0;            // 1: csr_wave_lockstep_kernel (8 waves per workgroup, sub-window chunk order; SCS_AMD_WR_LOCKSTEP)
+  int lockstep = 0;            // 1: csr_wave_lockstep_kernel (8 or 16 waves per workgroup, sub-window chunk order; SCS_AMD_WR_LOCKSTEP)
+  int ls_wpb = 8, ls_bmode = 4; // its waves per workgroup (SCS_AMD_WR_LS_WPB = 8 | 16) and barriers per chunk (SCS_AMD_WR_LS_BARRIERS = 4 | 2 | 1 | 0)
   int wpc = 8;                 // waves per CU the layout is cut for (one unit per resident wave); SCS_AMD_WR_WPC overrides (measurements)
   DevBuf<int> urow, useg;
   DevBuf<unsigned> wrd;
@@ -231,10 +231,10 @@ struct WaveRowsDev {
     const int resident = wpc * cus;
     const int rounds = std::max(1, (nunit + resident - 1) / resident);
     const int per_round = (nunit + rounds - 1) / rounds;
-    const int wpb = lockstep ? 8 : WR_WPB;
+    const int wpb = lockstep ? ls_wpb : WR_WPB;
     return std::max(1, std::min((per_round + wpb - 1) / wpb, WR_MAX_GRID));
   }
-  size_t lds_bytes() const { return (size_t)(lockstep ? 8 : WR_WPB) * accrows * sizeof(real); }
+  size_t lds_bytes() const { return (size_t)(lockstep ? ls_wpb : WR_WPB) * accrows * sizeof(real); }
   static int col_bits(int cols) {
     int b = 1;
     while ((1ll << b) < cols) ++b;
@@ -326,6 +326,8 @@ struct WaveRowsDev {
     if (const char *e = getenv("SCS_AMD_WR_LOCKSTEP")) { // 1: sub-window chunk order + lockstep kernel; 2: the order alone (plain kernel)
       lockstep = atoi(e) == 1 ? 1 : 0;
       sub_window_order = atoi(e) != 0;
+      if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 16 ? 16 : 8;
+      if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b);
     }
     if (sub_window_order) { // every 256-entry chunk: rank r in column order -> position 4 (r % 64) + r / 64 (see csr_wave_lockstep_kernel)
       std::vector<std::pair<unsigned, int>> key(256);

@@ -187,3 +187,90 @@ def test_psd_blocks_beyond_the_lds_path_match_reference(cone):
         assert np.abs(got - x0).max() > 1e-3
     lib._scs_finish_cone(c)
     ref._scs_finish_cone(wr)
+
+
+def _pack_psd(X):
+    """full symmetric k x k -> SCS's packed lower triangle, column-major, off-diagonals * sqrt(2) (src/cones.c:1018-1025)"""
+    k = X.shape[0]
+    out = []
+    for j in range(k):
+        col = X[j:, j].copy()
+        col[1:] *= np.sqrt(2.0)
+        out.append(col)
+    return np.concatenate(out)
+
+
+def _unpack_psd(v, k):
+    X = np.zeros((k, k))
+    o = 0
+    for j in range(k):
+        col = v[o:o + k - j].copy()
+        col[1:] /= np.sqrt(2.0)
+        X[j:, j] = col
+        X[j, j:] = col
+        o += k - j
+    return X
+
+
+@pytest.mark.parametrize("k", [512, 640])
+def test_large_psd_block_with_a_wide_eigenvalue_spread(k):
+    """the blocked Jacobi update used to compute tile (P, Q) and tile (Q, P) with independent matrix-core products
+    (symmetric only to rounding) while the inner sweep reads one triangle; round 4 writes the mirror tile from the same product.
+    A block of order >= 512 whose eigenvalues span 12 decades on both signs: the projection (dual cone of the PSD cone = the
+    PSD cone, r_y = NULL) must equal V max(L, 0) V' to 1e-9 of |A|, be exactly what a second call returns, and a projected
+    matrix must be a fixed point."""
+    lib = _lib()
+    rng = np.random.default_rng(k)
+    Q, _ = np.linalg.qr(rng.standard_normal((k, k)))
+    lam = np.concatenate([10.0 ** rng.uniform(-8, 4, k // 2), -(10.0 ** rng.uniform(-8, 4, k - k // 2))])
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    want = (Q * np.maximum(lam, 0)) @ Q.T
+    cone = dict(s=[k])
+    m = capi.cone_rows(cone)
+    kc = capi.make_cone(cone)
+    c = lib._scs_init_cone(C.byref(kc), m)
+    assert c
+    # Proj_{K*}(v) with K* = K for the PSD cone
+    x = _pack_psd(A)
+    got = x.copy()
+    assert lib._scs_proj_dual_cone(got.ctypes.data_as(T.fp), c, None, None) == 0
+    G = _unpack_psd(got, k)
+    scale = np.abs(A).max()
+    assert np.abs(G - want).max() <= 1e-9 * scale, np.abs(G - want).max() / scale
+    ev = np.linalg.eigvalsh(G)
+    assert ev.min() >= -1e-9 * scale
+    again = x.copy()                                   # second call: warm started from the carried eigenbasis
+    assert lib._scs_proj_dual_cone(again.ctypes.data_as(T.fp), c, None, None) == 0
+    assert np.abs(again - got).max() <= 1e-9 * scale
+    fix = got.copy()                                   # a PSD matrix is its own projection
+    assert lib._scs_proj_dual_cone(fix.ctypes.data_as(T.fp), c, None, None) == 0
+    assert np.abs(fix - got).max() <= 1e-9 * scale
+    lib._scs_finish_cone(c)
+
+
+@pytest.mark.parametrize("cone", [dict(s=[73, 80, 92, 50]), dict(s=[88], cs=[40, 46])])
+def test_lds_kernel_orders_73_to_92_warm_started_match_reference(cone):
+    """Round 4: the LDS Jacobi kernel carries the eigenbasis for EVERY order it handles (73..92 keep T = A Vp in an HBM scratch;
+    complex blocks of order 37..46 come through their real embedding of order 74..92).  A drifting sequence of projections -- cold,
+    then warm started from the previous basis -- against the reference's LAPACK path at 1e-11 each time."""
+    ref = _ref_lib()
+    lib = _lib()
+    Tr = ref._scs_types
+    m = capi.cone_rows(cone)
+    kr = capi.make_cone(cone, Tr)
+    wr = ref._scs_init_cone(C.byref(kr), m)
+    k = capi.make_cone(cone)
+    c = lib._scs_init_cone(C.byref(k), m)
+    assert c and wr
+    rng = np.random.default_rng(11)
+    x0 = rng.standard_normal(m)
+    for rep in range(6):
+        x0 = x0 + (0.3 if rep < 3 else 1e-3) * rng.standard_normal(m)   # large moves first, then the small ones warm starts are for
+        got, want = x0.copy(), x0.copy()
+        assert lib._scs_proj_dual_cone(got.ctypes.data_as(T.fp), c, None, None) == 0
+        assert ref._scs_proj_dual_cone(want.ctypes.data_as(Tr.fp), wr, None, None) == 0
+        err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        assert err <= 1e-11, (cone, rep, err)
+    lib._scs_finish_cone(c)
+    ref._scs_finish_cone(wr)

@@ -122,8 +122,8 @@ def test_linear_solve_with_the_admm_loops_zero_cone_weighting_matches_reference_
     """the full-size comparison above uses a uniform R_y; every real ADMM iteration weights the zero-cone
     rows 1000x (src/cones.c:349-363: R_y = 1/(1000 scale) there, 1/scale elsewhere), which multiplies the CG iterations.  Same
     comparison -- one scs_solve_lin_sys through the five-function ABI on both sides, warm start, tol 1e-9, the auto-selected
-    wave-owned-rows kernel -- WITH that weighting (z = 0.1 m, as the benchmark's cone recipe gives) at n = 5e5, m = 1e6,
-    nnz = 5e6, the largest size whose reference leg (OpenMP flavour, a child process with its own libgomp) fits a minute."""
+    wave-owned-rows kernel -- WITH that weighting (z = 0.1 m, as the benchmark's cone recipe gives) at the headline size itself,
+    n = 1e6, m = 2e6, nnz = 1e7 (the reference leg: OpenMP flavour in a child process with its own libgomp, well inside a minute)."""
     import os
     import subprocess
     import sys
@@ -132,7 +132,7 @@ def test_linear_solve_with_the_admm_loops_zero_cone_weighting_matches_reference_
     if not pyoracle.ref_available("libscsindir_ref_omp.so"):
         pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
     from tests import ref_linsys_child
-    n, m, z = 500000, 1000000, 100000
+    n, m, z = N, M, M // 10
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "ref.npy")
