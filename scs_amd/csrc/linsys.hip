@@ -705,6 +705,28 @@ LinSys::~LinSys() {
   if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
+// lockstep instantiations (experiment matrix of round 4): waves per workgroup x (barriers per chunk, gather-first pipeline)
+template <int E, int WPB, int MODE>
+static void launch_lockstep_one(const WaveRowsDev &wd, int g, size_t lds, hipStream_t stream, const WaveView &v, const real *x, real *y,
+                                const EpiArgs &e, const int *skip) {
+  static bool attr_set = false; // many waves' accumulators can pass the 64 KB a kernel gets without asking
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csr_wave_lockstep_kernel<E, WPB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  144 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((csr_wave_lockstep_kernel<E, WPB, MODE>), dim3(g), dim3(WPB * 64), lds, stream, v, x, y, e, skip, wd.accrows);
+}
+template <int E>
+static void launch_lockstep(const WaveRowsDev &wd, int g, size_t lds, hipStream_t stream, const WaveView &v, const real *x, real *y,
+                            const EpiArgs &e, const int *skip) {
+#define LS_CASE(W, M)                                                                                                  \
+  if (wd.ls_wpb == W && wd.ls_bmode == M) return launch_lockstep_one<E, W, M>(wd, g, lds, stream, v, x, y, e, skip);
+  LS_CASE(16, 4) LS_CASE(16, 12) LS_CASE(16, 9) LS_CASE(16, 8) LS_CASE(16, 1) LS_CASE(8, 4) LS_CASE(8, 12)
+#undef LS_CASE
+  throw HipError("scs_amd: lockstep SpMV variant not instantiated");
+}
+
 void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, const EpiArgs &e,
                          const int *skip) {
   int slot = -1;
@@ -718,14 +740,7 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
 #define WR_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
     if (wd.lockstep) {                                                                                                 \
-      static bool attr_set = false; /* many waves' accumulators can pass the 64 KB a kernel gets without asking */     \
-      if (!attr_set) {                                                                                                 \
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csr_wave_lockstep_kernel<E, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csr_wave_lockstep_kernel<E, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); \
-        attr_set = true;                                                                                               \
-      }                                                                                                                \
-      if (wd.ls_wpb == 16) hipLaunchKernelGGL((csr_wave_lockstep_kernel<E, 16>), dim3(g), dim3(1024), lds, stream, v, x, y, e, skip, wd.accrows, wd.ls_bmode); \
-      else hipLaunchKernelGGL((csr_wave_lockstep_kernel<E, 8>), dim3(g), dim3(512), lds, stream, v, x, y, e, skip, wd.accrows, wd.ls_bmode); \
+      launch_lockstep<E>(wd, g, lds, stream, v, x, y, e, skip);                                                        \
     } else if (wd.pipelined == 1) hipLaunchKernelGGL((csr_wave_kernel<E, 1>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
     else hipLaunchKernelGGL((csr_wave_kernel<E, 0>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows);                       \
   } while (0)
