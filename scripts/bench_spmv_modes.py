@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""SpMV time per product and wall time per CG iteration of one headline-family problem under several instantiations of the wave
+kernel (environment switches read by scs_init), for the decision which one the library picks by itself.
+    python scripts/bench_spmv_modes.py --cases 1000000:f64:0,200000:f64:0,4000000:f32:0,1000000:f64:1024 --modes plain,ls16,ls8
+One JSON line per (case, mode)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", default="1000000:f64:0")
+ap.add_argument("--modes", default="plain,ls16")
+ap.add_argument("--iters", type=int, default=30)
+a = ap.parse_args()
+import torch
+import bench
+MODES = {
+    "auto": {},
+    "plain": {"SCS_AMD_WR_LOCKSTEP": "0"},
+    "ls16": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "16", "SCS_AMD_WR_WPC": "16", "SCS_AMD_WR_LS_BARRIERS": "4"},
+    "ls16b1": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "16", "SCS_AMD_WR_WPC": "16", "SCS_AMD_WR_LS_BARRIERS": "1"},
+    "ls8": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "8", "SCS_AMD_WR_LS_BARRIERS": "4"},
+}
+KEYS = sorted({k for m in MODES.values() for k in m})
+args = argparse.Namespace(max_iters=20000)
+for case in a.cases.split(","):
+    n, dtype, band = case.split(":")
+    n, band = int(n), int(band)
+    pr = None
+    for mode in a.modes.split(","):
+        for k in KEYS:
+            os.environ.pop(k, None)
+        os.environ.update(MODES[mode])
+        s = bench.HipSolver(args, 0, 0, n, 2 * n, 10, 1234, 0, 1e-3 if dtype == "f32" else 1e-4, dtype=dtype, band=band or None, pr=pr)
+        pr = s.pr
+        s.begin(); s.steps(10)
+        st0 = s.stats(); s.profiling(True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        s.steps(a.iters)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        st1 = s.stats(); s.profiling(False); s.end(); s.close()
+        nl, ms = st1["spmv_launches"] - st0["spmv_launches"], st1["spmv_ms"] - st0["spmv_ms"]
+        cg = st1["cg_iters"] - st0["cg_iters"]
+        avg = ms / nl * 1e-3 if nl else float("nan")
+        bps = st1["spmv_bytes"] / 2.0
+        print(json.dumps(dict(n=n, dtype=dtype, band=band, mode=mode, spmv_avg_us=avg * 1e6, frac_of_8TBs=bps / avg / 1e9 / 8000.0 if nl else None,
+                              us_per_cg_iter=1e6 * el / cg if cg else None, cg_its_per_admm_iter=cg / float(a.iters), launches_timed=int(nl))), flush=True)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
 // of it): 512 gathers into one narrow window of x back to back, so that a line one wave pulled into the CU's L1 is still there when
 // another wave's gather wants it (the plain kernel measures 8.6 % L1 hits on the gathers; a CU's 39 K gathers per product touch
 // only 29 K - 33 K distinct lines).  Same entries, same units, same per-row summation order as the plain kernel ON THIS LAYOUT.
-template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4 | 1 | 0) + 8 for the gather-first pipeline
+template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4: in front of every gather instruction | 1)
 __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
                                                                         const int *skip, int accrows) {
   if (skip && *skip) return;
@@ -172,42 +172,7 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
     int nmax = 0;
 #pragma unroll
     for (int w = 0; w < WL_WPB; ++w) nmax = s_nch[w] > nmax ? s_nch[w] : nmax;
-    constexpr int bars = MODE & 7;          // barriers per chunk: 4 | 1 | 0
-    constexpr bool gather_first = (MODE & 8) != 0;
-    if (gather_first) {
-      // Phase order per chunk and CU: ALL waves' gathers of chunk c, THEN all waves' stream loads of chunk c + 1.  The CU's vector
-      // memory returns in order: a gather queued behind another wave's HBM stream load waits for it (why stream and gathers add up
-      // in the plain kernel, profiles/r2_g2_lab.md).  Aligned by the barrier, the gathers (L2 hits, bound by the 64 B/clk L1 fill)
-      // go first and the next chunk's stream loads ride behind them: their HBM latency overlaps the gathers' fill time and the
-      // LDS adds instead of preceding them.
-      // Branch free: every lane gathers (words past the unit's end are other units' entries or zero padding: valid columns), invalid
-      // lanes add +0.0 to accumulator 0 -- with divergent branches around the gathers the compiler's wait-count bookkeeping falls
-      // back to vmcnt(0) and would wait for the next chunk's stream loads too.
-      // (two chunks per trip with the roles of the two register sets swapped: a `cur = nxt` copy would have to wait for the loads)
-      auto step = [&](const WrChunk &cur, WrChunk &nxt, int c) {
-        const int eb = s + c * 256 + lane * 4;
-        const unsigned w[4] = {cur.w.x, cur.w.y, cur.w.z, cur.w.w};
-        real xx[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (bars == 4 || (bars == 2 && (i & 1) == 0) || (bars == 1 && i == 0)) __syncthreads();
-          xx[i] = x[w[i] & cmask];
-        }
-        __builtin_amdgcn_sched_barrier(0); // the next chunk's stream loads are issued BEHIND this chunk's gathers
-        nxt = wr_load(A, eb + 256);        // (past the last unit: the zero padding behind the arrays)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool ok = eb + i < t; // also false for a wave that is only keeping the others company
-          lds_add(acc + (ok ? (w[i] >> A.cbits) : 0u), ok ? cur.v[i] * xx[i] : (real)0);
-        }
-      };
-      WrChunk ca = wr_load(A, s + lane * 4), cb;
-      for (int c = 0; c < nmax; c += 2) {
-        step(ca, cb, c);
-        step(cb, ca, c + 1);
-      }
-    } else
+    constexpr int bars = MODE; // barriers per chunk: 4 | 1
     for (int c = 0; c < nmax; ++c) {
       const int eb = s + c * 256 + lane * 4;
       const bool has = c < nch; // wave-uniform: a wave whose unit is shorter keeps the others company at the barriers
@@ -337,7 +302,7 @@ struct WaveRowsDev {
       accrows = std::max(accrows, ur[u + 1] - ur[u]);
     }
     accrows = (accrows + 1) & ~1;
-    const size_t cap = q + 1024 + 8; // the last chunk of a unit may read up to 255 entries past its end (the gather-first lockstep kernel one chunk more)
+    const size_t cap = q + 256 + 8; // the last chunk of a unit may read up to 255 entries past its end
     if (cap >= ((size_t)1 << 31)) throw HipError("scs_amd: matrix too large for 32-bit entry offsets");
     std::vector<unsigned> hw(cap, 0u);
     std::vector<real> hv(cap, (real)0);
