@@ -694,8 +694,8 @@ def secondary_single_gpu(args, headline_prob=None):
             avg = ms / nl * 1e-3
             d["roofline"] = dict(bound="hbm", achieved=bps / avg / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bps / avg / 1e9 / HBM_PEAK_GBS,
                                  avg_launch_us=avg * 1e6, algorithmic_bytes_per_launch=bps, launches_timed=int(nl),
-                                 kernel="csr_wave_kernel, same layout as the headline; the library picks the instantiation with one chunk of "
-                                        "stream ahead of the gathers from the measured line sharing")
+                                 kernel="csr_wave_lockstep_kernel, same layout as the headline (one barrier per chunk instead of one per gather "
+                                        "instruction when the measured line sharing of the gathers is high)")
         out["locality_variant"][label] = d
 
     band_pr = None
@@ -897,7 +897,8 @@ def main():
         spmv_ms = stats1["spmv_ms"] - stats0["spmv_ms"]
         bytes_per_spmv = stats1["spmv_bytes"] / 2.0  # already computed with sizeof(scs_float) of the library
         roof = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                    kernel="csr_wave_kernel (wave-owned rows CSR SpMV, both orientations)")
+                    kernel="csr_wave_lockstep_kernel / csr_wave_kernel (wave-owned rows CSR SpMV, both orientations; the library picks the lockstep "
+                           "instantiation for fp64 systems from 5e6 nonzeros on, profiles/r4_spmv_lockstep.md)")
         if spmv_samples > 0 and spmv_ms > 0:
             avg_s = spmv_ms / spmv_samples * 1e-3
             roof["achieved"] = bytes_per_spmv / avg_s / 1e9
@@ -910,7 +911,8 @@ def main():
                 # CU's in-order memory queue): lab/g4_lab.hip ceiling test, profiles/r2_g4_lab.md section (1)/(4)
                 roof["l2_resident_ceiling_us"] = 0.5 * (57.2 + 64.3)
                 roof["launch_over_ceiling"] = roof["avg_launch_us"] / roof["l2_resident_ceiling_us"]
-                roof["ceiling_source"] = "profiles/r2_g4_lab.md (A 57.2 us, A' 64.3 us; gather-only 49/51 us, stream-only 27/26 us in the same kernel)"
+                roof["ceiling_source"] = ("profiles/r2_g4_lab.md (A 57.2 us, A' 64.3 us; gather-only 49/51 us, stream-only 27/26 us): measured on the PLAIN "
+                                          "kernel of rounds 2-3 (8 independent waves per CU); the lockstep instantiation of round 4 is a different schedule")
                 roof["ceiling_static"] = True  # a committed lab measurement, NOT taken in this run
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
         # only quoted for the exact workload it was measured on

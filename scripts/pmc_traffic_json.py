@@ -14,9 +14,9 @@ def per_kernel(db, min_us=20.0):
     c = sqlite3.connect(db)
     agg = {}
     for name, ctr, val, us in c.execute("select kernel_name, counter_name, value, (end-start)/1000.0 from counters_collection"):
-        if us < min_us or "csr_wave_kernel" not in name:
+        m = re.search(r"csr_wave(?:_lockstep)?_kernel<(\d+)", name)  # the plain / pipelined kernel or the lockstep instantiation
+        if us < min_us or not m:
             continue
-        m = re.search(r"csr_wave_kernel<(\d+)", name)
         a = agg.setdefault((int(m.group(1)), ctr), [0, 0.0, 0.0])
         a[0] += 1
         a[1] += val
@@ -26,7 +26,7 @@ def per_kernel(db, min_us=20.0):
 
 f, w = per_kernel(fetch_db), per_kernel(write_db)
 kern = {}
-for epi, nm, alg in ((1, "csr_wave_kernel<DIV> (A, m rows)", 152000004), (2, "csr_wave_kernel<GP> (A', n rows)", 148000004)):
+for epi, nm, alg in ((1, "csr_wave[_lockstep]_kernel<DIV> (A, m rows)", 152000004), (2, "csr_wave[_lockstep]_kernel<GP> (A', n rows)", 148000004)):
     fs, us, cnt = f[(epi, "FETCH_SIZE")]
     ws = w[(epi, "WRITE_SIZE")][0]
     hit, miss = w[(epi, "TCC_HIT_sum")][0], w[(epi, "TCC_MISS_sum")][0]
@@ -35,7 +35,7 @@ for epi, nm, alg in ((1, "csr_wave_kernel<DIV> (A, m rows)", 152000004), (2, "cs
 vals = list(kern.values())
 prof_us = None
 try:
-    rows = [l for l in open(stats_md) if "csr_wave_kernel<1" in l or "csr_wave_kernel<2" in l]
+    rows = [l for l in open(stats_md) if re.search(r"csr_wave(?:_lockstep)?_kernel<[12],", l)]
     prof_us = sum(float(r.split("|")[9]) for r in rows) / len(rows)  # "active avg us" column of scripts/rocpd_stats.py
 except Exception:
     pass

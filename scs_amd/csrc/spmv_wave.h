@@ -217,7 +217,8 @@ struct WaveRowsDev {
   double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
   int lockstep = 0;            // 1: csr_wave_lockstep_kernel (8 or 16 waves per workgroup, sub-window chunk order; SCS_AMD_WR_LOCKSTEP)
-  int ls_wpb = 8, ls_bmode = 4; // its waves per workgroup (SCS_AMD_WR_LS_WPB = 8 | 16) and barriers per chunk (SCS_AMD_WR_LS_BARRIERS = 4 | 2 | 1 | 0)
+  int sub_window_order = 0;    // every 256-entry chunk stored so that gather instruction i covers the i-th quarter of its column window
+  int ls_wpb = 16, ls_bmode = 4; // its waves per workgroup (SCS_AMD_WR_LS_WPB = 8 | 16) and barriers per chunk (SCS_AMD_WR_LS_BARRIERS = 4 | 1)
   int wpc = 8;                 // waves per CU the layout is cut for (one unit per resident wave); SCS_AMD_WR_WPC overrides (measurements)
   DevBuf<int> urow, useg;
   DevBuf<unsigned> wrd;
@@ -261,6 +262,20 @@ struct WaveRowsDev {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
       cus = 256;
+    // Lockstep instantiation (csr_wave_lockstep_kernel: one workgroup of 16 waves per CU, gathers issued together): measured faster for
+    // fp64 from ~5e6 nonzeros on, slower below and in fp32 (profiles/r4_spmv_lockstep.md); SCS_AMD_WR_LOCKSTEP = 0 | 1 forces either,
+    // 2 = its chunk order with the plain kernel
+    lockstep = (sizeof(real) == 8 && nnz_all >= 5000000LL) ? 1 : 0;
+    sub_window_order = lockstep;
+    ls_wpb = 16;
+    ls_bmode = -1; // chosen below from the measured line sharing unless SCS_AMD_WR_LS_BARRIERS says otherwise
+    if (const char *e = getenv("SCS_AMD_WR_LOCKSTEP")) {
+      lockstep = atoi(e) == 1 ? 1 : 0;
+      sub_window_order = atoi(e) != 0;
+    }
+    if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 8 ? 8 : 16;
+    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b) == 1 ? 1 : 4;
+    if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
     if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
     if (const char *e = getenv("SCS_AMD_WR_NNZ")) budget = std::max(64, atoi(e));
@@ -323,13 +338,6 @@ struct WaveRowsDev {
           hv[qq] = hval[k];
         }
     }
-    int sub_window_order = 0;
-    if (const char *e = getenv("SCS_AMD_WR_LOCKSTEP")) { // 1: sub-window chunk order + lockstep kernel; 2: the order alone (plain kernel)
-      lockstep = atoi(e) == 1 ? 1 : 0;
-      sub_window_order = atoi(e) != 0;
-      if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 16 ? 16 : 8;
-      if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b);
-    }
     if (sub_window_order) { // every 256-entry chunk: rank r in column order -> position 4 (r % 64) + r / 64 (see csr_wave_lockstep_kernel)
       std::vector<std::pair<unsigned, int>> key(256);
       std::vector<unsigned> tw(256);
@@ -374,6 +382,9 @@ struct WaveRowsDev {
       lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
       pipelined = lines_per_entry < 0.8 ? 1 : 0;
       if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
+      // lockstep: a barrier in front of every gather instruction when every gather is its own line, one per chunk when a unit's
+      // gathers share lines anyway (band of 1024 rows at the headline sizes: 34.0 vs 35.3 us per product; uniformly random: 65.1 vs 62.2)
+      if (ls_bmode < 0) ls_bmode = lines_per_entry < 0.3 ? 1 : 4;
     }
     urow.alloc(ur.size());
     useg.alloc(us.size());
