@@ -35,7 +35,7 @@ for epi, nm, alg in ((1, "csr_wave[_lockstep]_kernel<DIV> (A, m rows)", 15200000
 vals = list(kern.values())
 prof_us = None
 try:
-    rows = [l for l in open(stats_md) if re.search(r"csr_wave(?:_lockstep)?_kernel<[12],", l)]
+    rows = [l for l in open(stats_md) if re.search(r"csr_wave(?:_lockstep)?_kernel<[12],", l) and len(l.split("|")) >= 12]  # (not the gap table's rows)
     prof_us = sum(float(r.split("|")[9]) for r in rows) / len(rows)  # "active avg us" column of scripts/rocpd_stats.py
 except Exception:
     pass

@@ -36,7 +36,7 @@ constexpr int WR_MAX_GRID = 4096;   // partial-array bound for the fused dot pro
 constexpr int WR_BUCKETS = 1024;    // column buckets per unit (ordering heuristic only)
 
 struct WaveView {
-  int rows, nunit, cbits;
+  int rows, nunit, cbits, cols;
   const int *urow;     // nunit + 1 : first row of each unit
   const int *useg;     // 2 * nunit : [first entry (4-aligned), one past the last entry] of each unit
   const unsigned *wrd; // nnz : column | local row << cbits
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
 // of it): 512 gathers into one narrow window of x back to back, so that a line one wave pulled into the CU's L1 is still there when
 // another wave's gather wants it (the plain kernel measures 8.6 % L1 hits on the gathers; a CU's 39 K gathers per product touch
 // only 29 K - 33 K distinct lines).  Same entries, same units, same per-row summation order as the plain kernel ON THIS LAYOUT.
-template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4: in front of every gather instruction | 1)
+template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4: in front of every gather instruction | 1) + 8 x (x-window prefetch distance in chunks)
 __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
                                                                         const int *skip, int accrows) {
   if (skip && *skip) return;
@@ -172,7 +172,13 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
     int nmax = 0;
 #pragma unroll
     for (int w = 0; w < WL_WPB; ++w) nmax = s_nch[w] > nmax ? s_nch[w] : nmax;
-    constexpr int bars = MODE; // barriers per chunk: 4 | 1
+    constexpr int bars = MODE & 7; // barriers per chunk: 4 | 1
+    constexpr int pf = MODE >> 3;  // experiment: every wave touches its share of the window of x its XCD gathers from `pf` chunks later
+    const int lshift = sizeof(real) == 8 ? 4 : 5;
+    const int Lx = (A.cols + (1 << lshift) - 1) >> lshift;
+    const int wx = (int)(blockIdx.x >> 3) * WL_WPB + wave, nwx = (int)((gridDim.x + 7 - (blockIdx.x & 7)) >> 3) * WL_WPB;
+    const float wlen = (float)Lx / (float)(nmax > 0 ? nmax : 1);
+    const int per = (int)(wlen / (float)nwx) + 1;
     for (int c = 0; c < nmax; ++c) {
       const int eb = s + c * 256 + lane * 4;
       const bool has = c < nch; // wave-uniform: a wave whose unit is shorter keeps the others company at the barriers
@@ -180,6 +186,11 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
       ch.w = make_uint4(0, 0, 0, 0);
       ch.v[0] = ch.v[1] = ch.v[2] = ch.v[3] = 0;
       if (has) ch = wr_load(A, eb);
+      real pfv = 0;
+      if (pf > 0 && c + pf < nmax) {
+        const int ln = (int)((float)(c + pf) * wlen) + wx * per + lane;
+        if (lane < per && ln < Lx) pfv = x[(size_t)ln << lshift];
+      }
       const unsigned w[4] = {ch.w.x, ch.w.y, ch.w.z, ch.w.w};
       real xx[4];
 #pragma unroll
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (has && eb + i < t) lds_add(acc + (w[i] >> A.cbits), ch.v[i] * xx[i]);
+      if (pf > 0) asm volatile("" ::"v"(pfv));
     }
     for (int k = lane; k < nr; k += 64) {
       const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
@@ -223,7 +235,7 @@ struct WaveRowsDev {
   DevBuf<int> urow, useg;
   DevBuf<unsigned> wrd;
   DevBuf<real> val;
-  WaveView view() const { return WaveView{rows, nunit, cbits, urow.p, useg.p, wrd.p, val.p}; }
+  WaveView view() const { return WaveView{rows, nunit, cbits, cols, urow.p, useg.p, wrd.p, val.p}; }
   // every workgroup must be resident at once (8 waves per CU): a wave then walks its units one after the
   // other and all waves restart at column 0 together, which keeps the gather window of x aligned; a second
   // generation of workgroups starting at column 0 while the first is half way through thrashes L2 instead
@@ -274,7 +286,7 @@ struct WaveRowsDev {
       sub_window_order = atoi(e) != 0;
     }
     if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 8 ? 8 : 16;
-    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b) == 1 ? 1 : 4;
+    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b); // 4 | 1 (+ 8 x prefetch distance: experiment)
     if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
     if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
