@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
 // of it): 512 gathers into one narrow window of x back to back, so that a line one wave pulled into the CU's L1 is still there when
 // another wave's gather wants it (the plain kernel measures 8.6 % L1 hits on the gathers; a CU's 39 K gathers per product touch
 // only 29 K - 33 K distinct lines).  Same entries, same units, same per-row summation order as the plain kernel ON THIS LAYOUT.
-template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4: in front of every gather instruction | 1) + 8 x (x-window prefetch distance in chunks)
+template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4: in front of every gather instruction | 1) + 8: the next chunk's stream loads in flight ahead of the gathers
 __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
                                                                         const int *skip, int accrows) {
   if (skip && *skip) return;
@@ -173,24 +173,10 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
 #pragma unroll
     for (int w = 0; w < WL_WPB; ++w) nmax = s_nch[w] > nmax ? s_nch[w] : nmax;
     constexpr int bars = MODE & 7; // barriers per chunk: 4 | 1
-    constexpr int pf = MODE >> 3;  // experiment: every wave touches its share of the window of x its XCD gathers from `pf` chunks later
-    const int lshift = sizeof(real) == 8 ? 4 : 5;
-    const int Lx = (A.cols + (1 << lshift) - 1) >> lshift;
-    const int wx = (int)(blockIdx.x >> 3) * WL_WPB + wave, nwx = (int)((gridDim.x + 7 - (blockIdx.x & 7)) >> 3) * WL_WPB;
-    const float wlen = (float)Lx / (float)(nmax > 0 ? nmax : 1);
-    const int per = (int)(wlen / (float)nwx) + 1;
-    for (int c = 0; c < nmax; ++c) {
+    constexpr bool ahead = (MODE & 8) != 0;
+    auto consume = [&](const WrChunk &ch, int c) {
       const int eb = s + c * 256 + lane * 4;
       const bool has = c < nch; // wave-uniform: a wave whose unit is shorter keeps the others company at the barriers
-      WrChunk ch;
-      ch.w = make_uint4(0, 0, 0, 0);
-      ch.v[0] = ch.v[1] = ch.v[2] = ch.v[3] = 0;
-      if (has) ch = wr_load(A, eb);
-      real pfv = 0;
-      if (pf > 0 && c + pf < nmax) {
-        const int ln = (int)((float)(c + pf) * wlen) + wx * per + lane;
-        if (lane < per && ln < Lx) pfv = x[(size_t)ln << lshift];
-      }
       const unsigned w[4] = {ch.w.x, ch.w.y, ch.w.z, ch.w.w};
       real xx[4];
 #pragma unroll
@@ -202,7 +188,25 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (has && eb + i < t) lds_add(acc + (w[i] >> A.cbits), ch.v[i] * xx[i]);
-      if (pf > 0) asm volatile("" ::"v"(pfv));
+    };
+    WrChunk zero;
+    zero.w = make_uint4(0, 0, 0, 0);
+    zero.v[0] = zero.v[1] = zero.v[2] = zero.v[3] = 0;
+    if (ahead) { // chunk c + 1's stream loads are issued before chunk c's gathers (two register sets, roles swapped: no copies)
+      WrChunk ca = nch > 0 ? wr_load(A, s + lane * 4) : zero, cb = zero;
+      for (int c = 0; c < nmax; c += 2) {
+        cb = c + 1 < nch ? wr_load(A, s + (c + 1) * 256 + lane * 4) : zero;
+        consume(ca, c);
+        if (c + 1 < nmax) {
+          ca = c + 2 < nch ? wr_load(A, s + (c + 2) * 256 + lane * 4) : zero;
+          consume(cb, c + 1);
+        }
+      }
+    } else {
+      for (int c = 0; c < nmax; ++c) {
+        const WrChunk ch = c < nch ? wr_load(A, s + c * 256 + lane * 4) : zero;
+        consume(ch, c);
+      }
     }
     for (int k = lane; k < nr; k += 64) {
       const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
@@ -286,7 +290,7 @@ struct WaveRowsDev {
       sub_window_order = atoi(e) != 0;
     }
     if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 8 ? 8 : 16;
-    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b); // 4 | 1 (+ 8 x prefetch distance: experiment)
+    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b); // 4 | 1 (+ 8: stream ahead)
     if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
     if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
