@@ -18,8 +18,6 @@ MODES = {
     "ls16": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "16", "SCS_AMD_WR_WPC": "16", "SCS_AMD_WR_LS_BARRIERS": "4"},
     "ls16b1": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "16", "SCS_AMD_WR_WPC": "16", "SCS_AMD_WR_LS_BARRIERS": "1"},
     "ls8": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "8", "SCS_AMD_WR_LS_BARRIERS": "4"},
-    "ls16a": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "16", "SCS_AMD_WR_WPC": "16", "SCS_AMD_WR_LS_BARRIERS": "12"},   # + stream ahead
-    "ls16b1a": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "16", "SCS_AMD_WR_WPC": "16", "SCS_AMD_WR_LS_BARRIERS": "9"},
 }
 KEYS = sorted({k for m in MODES.values() for k in m})
 args = argparse.Namespace(max_iters=20000)

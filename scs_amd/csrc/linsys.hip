@@ -722,7 +722,7 @@ static void launch_lockstep(const WaveRowsDev &wd, int g, size_t lds, hipStream_
                             const EpiArgs &e, const int *skip) {
 #define LS_CASE(W, M)                                                                                                  \
   if (wd.ls_wpb == W && wd.ls_bmode == M) return launch_lockstep_one<E, W, M>(wd, g, lds, stream, v, x, y, e, skip);
-  LS_CASE(16, 4) LS_CASE(16, 1) LS_CASE(8, 4) LS_CASE(16, 12) LS_CASE(16, 9)
+  LS_CASE(16, 4) LS_CASE(16, 1) LS_CASE(8, 4)
 #undef LS_CASE
   throw HipError("scs_amd: lockstep SpMV variant not instantiated");
 }

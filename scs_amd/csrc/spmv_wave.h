@@ -136,13 +136,20 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
     }
   }
 }
-// Lockstep instantiation (round 4 experiment, SCS_AMD_WR_LOCKSTEP=1): ONE workgroup of 8 waves per CU; the host stores every 256-entry
-// chunk so that gather instruction i of a wave covers the i-th QUARTER of the chunk's column window (rank r of the chunk's entries in
-// column order sits at position 4 (r % 64) + r / 64), and the 8 waves of the CU issue gather instruction i together (a barrier in front
-// of it): 512 gathers into one narrow window of x back to back, so that a line one wave pulled into the CU's L1 is still there when
-// another wave's gather wants it (the plain kernel measures 8.6 % L1 hits on the gathers; a CU's 39 K gathers per product touch
-// only 29 K - 33 K distinct lines).  Same entries, same units, same per-row summation order as the plain kernel ON THIS LAYOUT.
-template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4: in front of every gather instruction | 1) + 8: the next chunk's stream loads in flight ahead of the gathers
+// Lockstep instantiation (round 4; the library's choice for fp64 systems from 5e6 nonzeros on, SCS_AMD_WR_LOCKSTEP = 0 | 1 forces either): ONE
+// workgroup of 16 waves per CU, one unit per wave (units half as long as the plain kernel's).  The host stores every 256-entry chunk so that
+// gather instruction i of a wave covers the i-th QUARTER of the chunk's column window (rank r of the chunk's entries in column order sits at
+// position 4 (r % 64) + r / 64), and a workgroup barrier in front of every gather instruction makes the 16 waves of the CU issue gather
+// instruction i of their chunk c together.  What that buys, measured (profiles/r4_spmv_lockstep.md, r4_pmc_l1*.md): 69.1 -> 62.2 us per product
+// on the headline (0.27 -> 0.30 of 8 TB/s), 39.0 -> 34.0 us on a band of 1024 rows (0.48 -> 0.55), 64.8 -> 51.3 us on a band of 65536.  NOT
+// mainly through L1 reuse -- the L1 -> L2 read requests per product fall by 3 % only (1.052e7 -> 1.016e7 / 1.085e7 -> 1.067e7) -- but through
+// the order of the CU's in-order vector-memory queue: with every wave of the CU in the same phase, a batch of L2-hit gathers is no longer
+// interleaved with other waves' HBM stream loads (TCP_PENDING_STALL_CYCLES -8 %), and sixteen waves' worth of gathers are in flight without
+// the drift that made sixteen UN-synchronised waves per CU slower than eight (91 vs 69 us, round 3).  Same per-wave LDS accumulators and
+// program-order adds as the plain kernel: bit-reproducible.  Variants measured and dropped: 8 waves per workgroup (66.4 us), one barrier per
+// chunk (65.1; kept for matrices whose gathers share lines: 34.0 vs 35.3 us on the band), the next chunk's stream loads issued behind the
+// gathers (67.3) or ahead of them (62.6), an x-window prefetch (73.7), 16 waves as two workgroups (69.7).
+template <int EPI, int WL_WPB, int MODE> // MODE = barriers per chunk (4: in front of every gather instruction | 1)
 __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e,
                                                                         const int *skip, int accrows) {
   if (skip && *skip) return;
@@ -172,8 +179,7 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
     int nmax = 0;
 #pragma unroll
     for (int w = 0; w < WL_WPB; ++w) nmax = s_nch[w] > nmax ? s_nch[w] : nmax;
-    constexpr int bars = MODE & 7; // barriers per chunk: 4 | 1
-    constexpr bool ahead = (MODE & 8) != 0;
+    constexpr int bars = MODE; // barriers per chunk: 4 | 1
     auto consume = [&](const WrChunk &ch, int c) {
       const int eb = s + c * 256 + lane * 4;
       const bool has = c < nch; // wave-uniform: a wave whose unit is shorter keeps the others company at the barriers
@@ -192,21 +198,9 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
     WrChunk zero;
     zero.w = make_uint4(0, 0, 0, 0);
     zero.v[0] = zero.v[1] = zero.v[2] = zero.v[3] = 0;
-    if (ahead) { // chunk c + 1's stream loads are issued before chunk c's gathers (two register sets, roles swapped: no copies)
-      WrChunk ca = nch > 0 ? wr_load(A, s + lane * 4) : zero, cb = zero;
-      for (int c = 0; c < nmax; c += 2) {
-        cb = c + 1 < nch ? wr_load(A, s + (c + 1) * 256 + lane * 4) : zero;
-        consume(ca, c);
-        if (c + 1 < nmax) {
-          ca = c + 2 < nch ? wr_load(A, s + (c + 2) * 256 + lane * 4) : zero;
-          consume(cb, c + 1);
-        }
-      }
-    } else {
-      for (int c = 0; c < nmax; ++c) {
-        const WrChunk ch = c < nch ? wr_load(A, s + c * 256 + lane * 4) : zero;
-        consume(ch, c);
-      }
+    for (int c = 0; c < nmax; ++c) {
+      const WrChunk ch = c < nch ? wr_load(A, s + c * 256 + lane * 4) : zero;
+      consume(ch, c);
     }
     for (int k = lane; k < nr; k += 64) {
       const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
@@ -290,7 +284,7 @@ struct WaveRowsDev {
       sub_window_order = atoi(e) != 0;
     }
     if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 8 ? 8 : 16;
-    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b); // 4 | 1 (+ 8: stream ahead)
+    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b) == 1 ? 1 : 4;
     if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
     if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));

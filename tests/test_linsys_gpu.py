@@ -208,3 +208,51 @@ def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(mon
         wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
         ref.scs_free_lin_sys_work(wr)
         assert np.abs(outs[0] - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize("wpb,bars,unit_nnz,wpc", [("16", "4", "600", None), ("16", "1", "1500", "1"), ("8", "4", "300", "2")])
+def test_lockstep_wave_kernel_matches_the_plain_one_and_the_reference(wpb, bars, unit_nnz, wpc, monkeypatch):
+    """Round 4: csr_wave_lockstep_kernel (one workgroup of 16 or 8 waves per CU issuing its gather instructions together, chunks
+    stored by quarter-windows; the library's choice for fp64 systems from 5e6 nonzeros on).  Forced on here at a size where the
+    reference finishes in seconds, with a unit budget small enough that the grid takes SEVERAL rounds and the waves of a workgroup
+    get units of different chunk counts (uneven rows: the matrix is tall with a few dense rows appended) -- a wave that runs out keeps
+    the others company at the barriers.  Same answer as the plain kernel (to rounding: the chunk order differs), as the csr-stream
+    kernel, and as the reference backend; identical bits from run to run."""
+    import scipy.sparse as sp
+    amd = capi.load("libscsamd_linsys.so")
+    n, m = 30000, 70001
+    A = probgen.random_csc(m - 40, n, 9, seed=21)
+    dense = sp.random(40, n, density=0.05, random_state=3, format="csc")   # 40 rows of ~1500 entries each: units of very different length
+    A = sp.vstack([A, dense]).tocsc()
+    A.sort_indices()
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m))
+    dr = probgen.diag_r(n, m, z=m // 10)
+    rng = np.random.default_rng(4)
+    b = rng.uniform(-1, 1, n + m)
+    s = rng.uniform(-1, 1, n) * 0.1
+    outs = {}
+    for name, env in (("stream", dict(SCS_AMD_WAVEROWS="0")),
+                      ("plain", dict(SCS_AMD_WAVEROWS="1", SCS_AMD_WR_LOCKSTEP="0", SCS_AMD_WR_NNZ=unit_nnz)),
+                      ("lockstep", dict(SCS_AMD_WAVEROWS="1", SCS_AMD_WR_LOCKSTEP="1", SCS_AMD_WR_LS_WPB=wpb, SCS_AMD_WR_LS_BARRIERS=bars,
+                                        SCS_AMD_WR_NNZ=unit_nnz)),
+                      ("lockstep_again", dict(SCS_AMD_WAVEROWS="1", SCS_AMD_WR_LOCKSTEP="1", SCS_AMD_WR_LS_WPB=wpb, SCS_AMD_WR_LS_BARRIERS=bars,
+                                              SCS_AMD_WR_NNZ=unit_nnz))):
+        for k in ("SCS_AMD_WAVEROWS", "SCS_AMD_WR_LOCKSTEP", "SCS_AMD_WR_LS_WPB", "SCS_AMD_WR_LS_BARRIERS", "SCS_AMD_WR_NNZ"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if wpc and name.startswith("lockstep"):
+            monkeypatch.setenv("SCS_AMD_WR_WPC", wpc)   # few resident waves per CU: the grid walks its units in several rounds
+        else:
+            monkeypatch.delenv("SCS_AMD_WR_WPC", raising=False)
+        w, out = _solve_with(amd, prob.matA, None, dr, b, s, 1e-12)
+        amd.scs_free_lin_sys_work(w)
+        outs[name] = out
+    scale = np.abs(outs["stream"]).max()
+    assert np.array_equal(outs["lockstep"], outs["lockstep_again"])            # deterministic
+    assert np.abs(outs["lockstep"] - outs["plain"]).max() <= 1e-9 * scale
+    assert np.abs(outs["lockstep"] - outs["stream"]).max() <= 1e-9 * scale
+    ref = _ref()
+    wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
+    ref.scs_free_lin_sys_work(wr)
+    assert np.abs(outs["lockstep"] - xr).max() <= 1e-8 * np.abs(xr).max()
