@@ -82,3 +82,22 @@ def test_default_schedule_to_termination_warm_start_and_update_through_the_renum
     lib.scs_finish(w)
     fresh = capi.solve(lib, capi.Problem(scr["A"], b2, c2, scr["cone"]), verbose=0, acceleration_lookback=0, max_iters=100)
     assert inf.iter == fresh["info"]["iter"] and np.array_equal(x, fresh["x"]) and np.array_equal(s, fresh["s"])
+
+
+def test_pure_lp_renumbered_through_the_graph_search_gives_the_same_answer(monkeypatch):
+    """no row that cannot move (zero + nonnegative cones only): scs_init renumbers both the variables and ALL rows (Cuthill-McKee);
+    same answer as with the renumbering off, in the caller's numbering"""
+    lib = capi.load("libscsamd.so")
+    n, m = 20000, 50000
+    cone = dict(z=15000, l=35000, q=[])
+    scr = problems.scramble_prob(problems.random_cone_prob(n, m, 8, cone, seed=31, band=400), 2)
+    monkeypatch.setenv("SCS_AMD_REORDER", "0")
+    off, _ = _solve(lib, scr, cg_tol_override=1e-12, max_iters=120)
+    monkeypatch.setenv("SCS_AMD_REORDER", "1")
+    on, prob = _solve(lib, scr, cg_tol_override=1e-12, max_iters=120)
+    assert _reorder_info(lib, prob)[0] == 1.0
+    for v in ("x", "y", "s"):
+        d = np.abs(on[v] - off[v]).max() / max(1.0, np.abs(off[v]).max())
+        assert d <= 1e-9, (v, d)
+    for k in ("pobj", "dobj", "res_pri", "res_dual", "gap"):
+        assert abs(on["info"][k] - off["info"][k]) <= 1e-8 * max(1.0, abs(off["info"][k])), k

@@ -44,6 +44,8 @@ def test_thread_ranks_on_one_gpu_match_the_unsplit_solve(world):
     s = rng.uniform(-1, 1, n) * 0.1
     want, its = _unsplit(A, dr, b, s, 1e-11)
     want2, _ = _unsplit(A, dr, 2 * b, None, 1e-11)
+    dr2 = probgen.diag_r(n, m, z=m // 10, scale=0.7)     # what a scale update of the ADMM loop hands to the backend
+    want3, _ = _unsplit(A, dr2, b, s, 1e-11)
     group = lib.scs_amd_shard_group_create(world)
     assert group
     res, err = [None] * world, []
@@ -53,7 +55,13 @@ def test_thread_ranks_on_one_gpu_match_the_unsplit_solve(world):
             S = shard.NativeShardedLinSys(A, dr, world=world, rank=r, group=group, lib=lib)
             x, y = S.solve(b, s, tol=1e-11)
             x2, y2 = S.solve(2 * b, None, tol=1e-11)  # a second, cold-started solve on the same workspaces
-            res[r] = (x, y, x2, y2, S.stats(), (S.r0, S.r1))
+            st = S.stats()
+            # scs_update_lin_sys_diag_r of the split system (collective: the preconditioner is re-summed over the ranks)
+            T = lib._scs_types
+            loc = np.concatenate([dr2[:n] / world, dr2[n + S.r0:n + S.r1]]).astype(T.np_float)
+            assert lib.scs_amd_shard_update_diag_r(S.h, loc.ctypes.data_as(T.fp)) == 0
+            x3, y3 = S.solve(b, s, tol=1e-11)
+            res[r] = (x, y, x2, y2, st, (S.r0, S.r1), x3, y3)
             S.close()
         except Exception as e:  # (a rank that dies would leave the others waiting in the barrier: report and let the test time out)
             err.append(repr(e))
@@ -76,6 +84,8 @@ def test_thread_ranks_on_one_gpu_match_the_unsplit_solve(world):
         assert st["solves"] == 2 and abs(st["cg_iters"] - res[0][4]["cg_iters"]) == 0
         assert st["allreduces"] >= st["cg_iters"]                   # one n-vector all-reduce per CG iteration (+ setup)
     assert np.abs(y - want[n:]).max() <= 1e-8 * sc
+    y3 = np.concatenate([r[7] for r in res])
+    assert np.abs(res[0][6] - want3[:n]).max() <= 1e-8 * np.abs(want3).max() and np.abs(y3 - want3[n:]).max() <= 1e-8 * np.abs(want3).max()
     assert 0.5 * its <= res[0][4]["cg_iters"] / 2 <= 2.5 * its      # same algorithm: comparable iteration counts
     from oracle import pyoracle
     if pyoracle.ref_available():
