@@ -285,6 +285,7 @@ struct WaveRowsDev {
     }
     if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 8 ? 8 : 16;
     if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b) == 1 ? 1 : 4;
+    if (const char *o = getenv("SCS_AMD_WR_LS_ORDER")) sub_window_order = atoi(o) != 0; // measurements: lockstep without the quarter-window chunk order
     if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
     if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
