@@ -25,7 +25,8 @@ namespace scsamd {
 
 struct BigPsdCtl {
   real thr, fro;
-  unsigned long long offmax_bits; // bit pattern of the largest |a_pq| met in this sweep (non-negative: orders like the value)
+  unsigned long long offmax_bits[2]; // bit pattern of the largest |a_pq| met in a sweep (non-negative: orders like the value), by sweep parity:
+                                     // the fused step (k_bj_fused) runs the first inner sweep of sweep s + 1 before sweep s is closed
   int cur[2];                     // which A copy holds the block before launch g: cur[g & 1] (written for g+1 by the launch itself)
   int done, sweeps, kraw; // kraw: signed order (negative = complex embedding), copied here so that a step kernel
                           // needs ONE dependent read (this record) before it touches A
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(BP_PARAM_THREADS) void k_bp_norm(BigPsdView B) {
     c->fro = fro;
     // same rule as k_psd_jacobi (fp32: not below the rounding noise of the rotations)
     c->thr = sizeof(real) == 8 ? eps * fro / (real)s.k : fmaxf(eps * fro / (real)s.k, (real)2.4e-7 * fro);
-    c->offmax_bits = 0ull;
+    c->offmax_bits[0] = c->offmax_bits[1] = 0ull;
     c->cur[0] = c->cur[1] = 0;
     c->done = fro > (real)0 ? 0 : 1;
     c->sweeps = 0;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_step(BigPsdView B, int arg) {
           const real w = __shfl_down(mx, o, 64);
           mx = w > mx ? w : mx;
         }
-        if (tid == 0 && mx > (real)0) atomicMax(&ctl->offmax_bits, bp_bits(mx));
+        if (tid == 0 && mx > (real)0) atomicMax(&ctl->offmax_bits[ctl->sweeps & 1], bp_bits(mx));
       }
     }
     __syncthreads();
@@ -258,10 +259,12 @@ constexpr int BJ_INNER_THREADS = 512;
 #else
 constexpr int BJ_INNER_THREADS = BJ_INNER_THREADS_OVERRIDE;
 #endif
+constexpr int BJ_UPD_THREADS_MAX = 1024;                // largest workgroup that runs bj_inner_sweep (k_bj_fused)
 constexpr int BJ_NBLK = BJ_B * BJ_B / BJ_INNER_THREADS; // 2x2 blocks of S per lane and inner step
 constexpr int BJ_NROW = BJ_W * BJ_B / BJ_INNER_THREADS; // row pairs of Q per lane and inner step
 static_assert(BJ_NBLK * BJ_INNER_THREADS == BJ_B * BJ_B && BJ_NROW * BJ_INNER_THREADS == BJ_W * BJ_B, "k_bj_inner: whole items per lane");
-constexpr size_t BJ_INNER_LDS = (size_t)2 * BJ_W * BJ_ILD * sizeof(real) + BJ_B * (sizeof(RotCS) + sizeof(int2));
+constexpr size_t BJ_INNER_LDS = (size_t)3 * BJ_W * BJ_ILD * sizeof(real) + 2 * BJ_B * sizeof(RotCS); // S (two copies), Q, two generations of (c, s)
+constexpr int BJ_INNER_LAUNCH = BJ_INNER_THREADS + SCSAMD_WAVE;                                         // the workers and the wave that forms the rotations
 constexpr size_t BJ_UPDATE_LDS = (size_t)4 * BJ_W * BJ_LD * sizeof(real);
 
 __device__ __forceinline__ int2 bj_pair(int i, int step, int nbc) { // round robin over block columns, as over columns
@@ -307,35 +310,45 @@ __device__ __forceinline__ int2 bj_inner_pair(int i, int st, int kind) { // kind
   }
   return make_int2(p, q);
 }
+template <int KIND> __device__ __forceinline__ int2 bj_inner_pair_k(int i, int st) { // the same with the kind known at compile time (no run-time modulus)
+  if (KIND == 2) return make_int2(i, BJ_B + ((i + st) & (BJ_B - 1)));
+  constexpr int n = KIND == 1 ? BJ_B : BJ_W;
+  const int j = KIND == 1 ? (i & (BJ_B / 2 - 1)) : i, off = KIND == 1 && i >= BJ_B / 2 ? BJ_B : 0;
+  int p = j == 0 ? 0 : 1 + ((j - 1 + st) % (n - 1));
+  int q = 1 + ((n - 2 - j + st) % (n - 1));
+  if (p > q) {
+    const int t = p;
+    p = q;
+    q = t;
+  }
+  return make_int2(p + off, q + off);
+}
 // global row / column of local index l (0..63) of the pair (I, J)
 __device__ __forceinline__ int bj_gidx(int2 IJ, int l) { return l < BJ_B ? IJ.x * BJ_B + l : IJ.y * BJ_B + (l - BJ_B); }
 
-// Qbuf / Sbuf: per (block, pair) 64 x 64 column-major; Qflag: 1 if the sweep rotated anything
-__global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, real *Qbuf, real *Sbuf, int *Qflag, int npmax, int arg, int cross) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
-  real *S = reinterpret_cast<real *>(bj_smem);
-  real *Q = S + BJ_W * BJ_ILD;
+// The inner sweep proper, on the subproblem already in LDS (S[r * BJ_ILD + c]); Q <- I here.  Every thread of the workgroup calls it;
+// threads beyond BJ_INNER_THREADS only keep the barriers company (the fused step runs it in a workgroup of BJ_UPD_THREADS).
+// Leaves Q, S' and the "rotated at all" flag in HBM (Qg / Sg: 64 x 64 column-major) and the sweep's off-diagonal maximum in the
+// control record (slot `offslot`).
+// A step is two phases and two barriers: 32 lanes form the rotations (three LDS reads, fp64 rsqrt chain: ~840 clocks measured), then
+// 1024 2x2 blocks of S and 2048 row pairs of Q over the lanes: every lane owns BJ_NBLK blocks and BJ_NROW row pairs and asks for
+// everything it needs -- the (c, s) of its pairs, its operands, the "any rotation" flag -- in ONE batch of LDS reads: the pair indices
+// are arithmetic (the kind of sweep is a template parameter), so no address depends on a table.  (With the pairs read from a table
+// the phase was three dependent LDS round trips: 1830 clocks.)
+template <int KIND>
+__device__ __forceinline__ void bj_inner_sweep_k(unsigned char *smem, int2 IJ, int k, real thr, BigPsdCtl *ctl, int offslot, real *Qg, real *Sg,
+                                                 int *flag_out) {
+  real *S = reinterpret_cast<real *>(smem);
+  real *Q = S + 2 * BJ_W * BJ_ILD; // (the second copy of S between them is the cross sweep's)
   RotCS *rot_cs = reinterpret_cast<RotCS *>(Q + BJ_W * BJ_ILD);
-  int2 *rot_pq = reinterpret_cast<int2 *>(rot_cs + BJ_B);
-  __shared__ real red[BJ_INNER_THREADS / SCSAMD_WAVE];
+  __shared__ real red[BJ_UPD_THREADS_MAX / SCSAMD_WAVE];
   __shared__ volatile int rot_any[2];
   __shared__ int rotated;
-  const int slot = arg & 1, step = arg >> 1;
-  const int b = blockIdx.y, pi = blockIdx.x, tid = threadIdx.x;
-  BigPsdCtl *ctl = B.ctl + b;
-  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
-  const real thr = ctl->thr;
-  const BlockShape sh = bp_shape_raw(kraw);
-  if (done || step >= bj_outer_steps(sh.nbc, cross) || pi >= sh.nbc / 2) return;
-  const int2 IJ = bj_pair_sched(pi, step, sh.nbc, cross);
-  const int kind = !cross ? 0 : (step == 0 ? 1 : 2);
-  const int nst = kind == 0 ? BJ_W - 1 : (kind == 1 ? BJ_B - 1 : BJ_B);
-  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
-  const real *Aold = (cur ? B.A1 : B.A) + mat;
-  const int k = sh.k;
-  for (int e = tid; e < BJ_W * BJ_W; e += BJ_INNER_THREADS) {
-    const int r = e & (BJ_W - 1), c = e >> 6; // r fast: 32-entry runs of a column of A
-    S[r * BJ_ILD + c] = Aold[(size_t)bj_gidx(IJ, c) * ld + bj_gidx(IJ, r)];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const bool worker = tid < BJ_INNER_THREADS;
+  constexpr int nst = KIND == 0 ? BJ_W - 1 : (KIND == 1 ? BJ_B - 1 : BJ_B);
+  for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
+    const int r = e & (BJ_W - 1), c = e >> 6;
     Q[r * BJ_ILD + c] = r == c ? (real)1 : (real)0;
   }
   if (tid < 2) rot_any[tid] = 0;
@@ -347,57 +360,38 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
     const int par = st & 1;
     if (tid < NP) {
       const int i = tid;
-      const int2 pq_i = bj_inner_pair(i, st, kind);
+      const int2 pq_i = bj_inner_pair_k<KIND>(i, st);
       const int p = pq_i.x, q = pq_i.y;
       real c = 1, s = 0;
-      const real apq = S[p * BJ_ILD + q];
+      const real apq = S[p * BJ_ILD + q], aqq = S[q * BJ_ILD + q], app = S[p * BJ_ILD + p];
       const real aa = absval(apq);
       const bool real_pair = bj_gidx(IJ, q) < k; // local order = global order (I < J): q is the larger index
       if (real_pair) offmax = aa > offmax ? aa : offmax;
       if (real_pair && aa > thr) {
-        const real d = S[q * BJ_ILD + q] - S[p * BJ_ILD + p], bb = (real)2 * apq;
-        jacobi_cs(d, bb, c, s);
+        jacobi_cs(aqq - app, (real)2 * apq, c, s);
         rot_any[par] = 1;
       }
-      rot_pq[i] = make_int2(p, q);
       rot_cs[i] = RotCS{c, s};
       if (i == 0) rot_any[par ^ 1] = 0;
     }
     __syncthreads();
-    if (!rot_any[par]) continue; // uniform
-    if (tid == 0) rotated = 1;
-    // 1024 2x2 blocks of S and 2048 row pairs of Q over the lanes: every lane owns BJ_NBLK blocks and BJ_NROW row pairs, and asks
-    // for all its tables, then all its operands, before it computes -- the LDS round trips of the six items overlap
-    // instead of queueing behind each other (an item loop measured 96 us per sweep: six dependent round trips per step)
-    {
-      int i11[BJ_NBLK], i12[BJ_NBLK], i21[BJ_NBLK], i22[BJ_NBLK];
-      RotCS r1[BJ_NBLK], r2[BJ_NBLK];
-      bool own[BJ_NBLK];
+    const int any = rot_any[par]; // uniform over the workgroup (nobody sets this parity again before the next step's barrier)
+    if (worker) {
+      int i11[BJ_NBLK], i12[BJ_NBLK], i21[BJ_NBLK], i22[BJ_NBLK], ip[BJ_NROW], iq[BJ_NROW];
+      RotCS r1[BJ_NBLK], r2[BJ_NBLK], rq[BJ_NROW];
+      real a11[BJ_NBLK], a12[BJ_NBLK], a21[BJ_NBLK], a22[BJ_NBLK], vp[BJ_NROW], vq[BJ_NROW];
+      bool same[BJ_NBLK];
 #pragma unroll
       for (int u = 0; u < BJ_NBLK; ++u) {
         const int e = tid + u * BJ_INNER_THREADS, Qi = e / NP, P = e % NP;
-        const int2 pq1 = rot_pq[P], pq2 = rot_pq[Qi];
-        r1[u] = rot_cs[P];
-        r2[u] = rot_cs[Qi];
+        const int2 pq1 = bj_inner_pair_k<KIND>(P, st), pq2 = bj_inner_pair_k<KIND>(Qi, st);
         i11[u] = pq1.x * BJ_ILD + pq2.x;
         i12[u] = pq1.x * BJ_ILD + pq2.y;
         i21[u] = pq1.y * BJ_ILD + pq2.x;
         i22[u] = pq1.y * BJ_ILD + pq2.y;
-        own[u] = P == Qi && r1[u].s != (real)0;
-      }
-      int ip[BJ_NROW], iq[BJ_NROW];
-      RotCS rq[BJ_NROW];
-#pragma unroll
-      for (int j = 0; j < BJ_NROW; ++j) {
-        const int f = tid + j * BJ_INNER_THREADS, Qi = f / BJ_W, i = f % BJ_W;
-        const int2 pq2 = rot_pq[Qi];
-        rq[j] = rot_cs[Qi];
-        ip[j] = i * BJ_ILD + pq2.x;
-        iq[j] = i * BJ_ILD + pq2.y;
-      }
-      real a11[BJ_NBLK], a12[BJ_NBLK], a21[BJ_NBLK], a22[BJ_NBLK], vp[BJ_NROW], vq[BJ_NROW];
-#pragma unroll
-      for (int u = 0; u < BJ_NBLK; ++u) {
+        same[u] = P == Qi;
+        r1[u] = rot_cs[P];
+        r2[u] = rot_cs[Qi];
         a11[u] = S[i11[u]];
         a12[u] = S[i12[u]];
         a21[u] = S[i21[u]];
@@ -405,39 +399,229 @@ __global__ __launch_bounds__(BJ_INNER_THREADS) void k_bj_inner(BigPsdView B, rea
       }
 #pragma unroll
       for (int j = 0; j < BJ_NROW; ++j) {
+        const int f = tid + j * BJ_INNER_THREADS, Qi = f / BJ_W, i = f % BJ_W;
+        const int2 pq2 = bj_inner_pair_k<KIND>(Qi, st);
+        ip[j] = i * BJ_ILD + pq2.x;
+        iq[j] = i * BJ_ILD + pq2.y;
+        rq[j] = rot_cs[Qi];
         vp[j] = Q[ip[j]];
         vq[j] = Q[iq[j]];
       }
+      if (any) { // a step in which no pair is above the threshold changes nothing
 #pragma unroll
-      for (int u = 0; u < BJ_NBLK; ++u) {
-        const real c1 = r1[u].c, s1 = r1[u].s, c2 = r2[u].c, s2 = r2[u].s;
-        const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
-        const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
-        S[i11[u]] = c2 * r11 - s2 * r12;
-        S[i12[u]] = own[u] ? (real)0 : s2 * r11 + c2 * r12;
-        S[i21[u]] = own[u] ? (real)0 : c2 * r21 - s2 * r22;
-        S[i22[u]] = s2 * r21 + c2 * r22;
-      }
+        for (int u = 0; u < BJ_NBLK; ++u) {
+          const real c1 = r1[u].c, s1 = r1[u].s, c2 = r2[u].c, s2 = r2[u].s;
+          const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
+          const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
+          const bool own = same[u] && s1 != (real)0; // the rotated pair's own off-diagonal entry: exact zero
+          S[i11[u]] = c2 * r11 - s2 * r12;
+          S[i12[u]] = own ? (real)0 : s2 * r11 + c2 * r12;
+          S[i21[u]] = own ? (real)0 : c2 * r21 - s2 * r22;
+          S[i22[u]] = s2 * r21 + c2 * r22;
+        }
 #pragma unroll
-      for (int j = 0; j < BJ_NROW; ++j) {
-        Q[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
-        Q[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
+        for (int j = 0; j < BJ_NROW; ++j) {
+          Q[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
+          Q[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
+        }
+        if (tid == 0) rotated = 1;
       }
     }
+    if (!any) continue; // nothing was written: the next step's rotations may be formed at once
     __syncthreads();
   }
   offmax = block_max(offmax, red); // (contains the barriers that make `rotated` and the last pass visible)
   if (tid == 0) {
-    if (offmax > (real)0) atomicMax(&ctl->offmax_bits, bp_bits(offmax));
-    Qflag[(size_t)b * npmax + pi] = rotated;
+    if (offmax > (real)0) atomicMax(&ctl->offmax_bits[offslot], bp_bits(offmax));
+    *flag_out = rotated;
   }
   if (!rotated) return; // uniform: nobody reads Q / S' of a pair whose flag is 0
-  real *Qg = Qbuf + ((size_t)b * npmax + pi) * BJ_W * BJ_W, *Sg = Sbuf + ((size_t)b * npmax + pi) * BJ_W * BJ_W;
-  for (int e = tid; e < BJ_W * BJ_W; e += BJ_INNER_THREADS) {
+  for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
     const int r = e & (BJ_W - 1), c = e >> 6;
     Qg[c * BJ_W + r] = Q[r * BJ_ILD + c];
     Sg[c * BJ_W + r] = S[r * BJ_ILD + c];
   }
+}
+// one 2x2 block of J' S J: rows rotated by (c1, s1), then columns by (c2, s2); `own`: the block of a rotated pair with itself, whose
+// off-diagonal entries are exact zeros.  ONE definition (explicit fused multiply-adds) for the lanes that update S and the lanes that
+// look one step ahead, so that both get the same bits.
+struct Blk2 {
+  real n11, n12, n21, n22;
+};
+__device__ __forceinline__ Blk2 bj_block(real a11, real a12, real a21, real a22, RotCS r1, RotCS r2, bool own) {
+  const real r11 = fma(r1.c, a11, -(r1.s * a21)), r12 = fma(r1.c, a12, -(r1.s * a22));
+  const real r21 = fma(r1.s, a11, r1.c * a21), r22 = fma(r1.s, a12, r1.c * a22);
+  Blk2 o;
+  o.n11 = fma(r2.c, r11, -(r2.s * r12));
+  o.n12 = own ? (real)0 : fma(r2.s, r11, r2.c * r12);
+  o.n21 = own ? (real)0 : fma(r2.c, r21, -(r2.s * r22));
+  o.n22 = fma(r2.s, r21, r2.c * r22);
+  return o;
+}
+
+// The CROSS sweep (pairs p in I, q in J; 32 steps; 31 of the 32 launches of a sweep of a 1024 x 1024 block), software-pipelined: the
+// clocks of the two-phase step above are 910 (rotations: 32 lanes, an LDS round trip, the rsqrt chain, a barrier) + 2020 (update:
+// bound by the vector ALUs' instruction issue, ~150 instructions per wave and step of which 48 are the fp64 arithmetic, and a barrier)
+// (profiles/r4_psd_inner_phases.md).  Here the rotations of step st + 1 are formed DURING the update of step st, by a wave that does
+// nothing else: S is double-buffered (the update reads one copy and writes the other), so the look-ahead lanes can read the old
+// entries while they are being replaced, and apply the current step's rotations to just the three entries their next pair needs
+// (S[p'][p'], S[q'][q'], S[p'][q']: three 2x2 blocks, the same bj_block as the update, hence the same bits).  One barrier per step.
+// Round 3 measured this form slower (114 vs 96 us per sweep): the look-ahead chain then went through pair tables and an fp64
+// sqrt / div / rsqrt sequence and was longer than the update; with arithmetic pairs and the two-rsqrt jacobi_cs it is shorter.
+__device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 IJ, int k, real thr, BigPsdCtl *ctl, int offslot, real *Qg, real *Sg,
+                                                     int *flag_out) {
+  real *S0 = reinterpret_cast<real *>(smem);
+  real *Q = S0 + 2 * BJ_W * BJ_ILD;
+  RotCS *rot_cs = reinterpret_cast<RotCS *>(Q + BJ_W * BJ_ILD); // [2][BJ_B]: generation st & 1 holds the rotations of step st
+  __shared__ real red[BJ_UPD_THREADS_MAX / SCSAMD_WAVE];
+  __shared__ volatile int rot_any[2];
+  __shared__ int rotated;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const bool worker = tid < BJ_INNER_THREADS;
+  const bool ahead = tid >= BJ_INNER_THREADS && tid < BJ_INNER_THREADS + BJ_B; // the 32 lanes that form the rotations
+  const int ai = tid - BJ_INNER_THREADS;                                        // their pair
+  constexpr int NP = BJ_B, nst = BJ_B;
+  for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
+    const int r = e & (BJ_W - 1), c = e >> 6;
+    Q[r * BJ_ILD + c] = r == c ? (real)1 : (real)0;
+  }
+  if (tid < 2) rot_any[tid] = 0;
+  if (tid == 0) rotated = 0;
+  __syncthreads();
+  real offmax = 0;
+  // the rotation of pair (p, q) from its three entries; records it as generation `gen`
+  auto form = [&](int gen, int q, real app, real aqq, real apq) {
+    real c = 1, s = 0;
+    const real aa = absval(apq);
+    const bool real_pair = bj_gidx(IJ, q) < k; // local order = global order (I < J): q is the larger index
+    if (real_pair) offmax = aa > offmax ? aa : offmax;
+    if (real_pair && aa > thr) {
+      jacobi_cs(aqq - app, (real)2 * apq, c, s);
+      rot_any[gen] = 1;
+    }
+    rot_cs[gen * BJ_B + ai] = RotCS{c, s};
+  };
+  if (ahead) { // step 0's rotations from the matrix as loaded
+    const int p = ai, q = BJ_B + ai;
+    form(0, q, S0[p * BJ_ILD + p], S0[q * BJ_ILD + q], S0[p * BJ_ILD + q]);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int st = 0; st < nst; ++st) {
+    const int gen = st & 1;
+    const real *Sr = S0 + cur * BJ_W * BJ_ILD;
+    real *Sw = S0 + (cur ^ 1) * BJ_W * BJ_ILD;
+    const RotCS *cs = rot_cs + gen * BJ_B;
+    const int any = rot_any[gen]; // uniform (set before the barrier that ended the previous step)
+    if (worker) {
+      if (any) { // a step in which no pair is above the threshold changes nothing
+        int i11[BJ_NBLK], i12[BJ_NBLK], i21[BJ_NBLK], i22[BJ_NBLK], ip[BJ_NROW], iq[BJ_NROW];
+        RotCS r1[BJ_NBLK], r2[BJ_NBLK], rq[BJ_NROW];
+        real a11[BJ_NBLK], a12[BJ_NBLK], a21[BJ_NBLK], a22[BJ_NBLK], vp[BJ_NROW], vq[BJ_NROW];
+        bool same[BJ_NBLK];
+#pragma unroll
+        for (int u = 0; u < BJ_NBLK; ++u) {
+          const int e = tid + u * BJ_INNER_THREADS, Qi = e / NP, P = e % NP;
+          const int q1 = BJ_B + ((P + st) & (BJ_B - 1)), q2 = BJ_B + ((Qi + st) & (BJ_B - 1));
+          i11[u] = P * BJ_ILD + Qi;
+          i12[u] = P * BJ_ILD + q2;
+          i21[u] = q1 * BJ_ILD + Qi;
+          i22[u] = q1 * BJ_ILD + q2;
+          same[u] = P == Qi;
+          r1[u] = cs[P];
+          r2[u] = cs[Qi];
+          a11[u] = Sr[i11[u]];
+          a12[u] = Sr[i12[u]];
+          a21[u] = Sr[i21[u]];
+          a22[u] = Sr[i22[u]];
+        }
+#pragma unroll
+        for (int j = 0; j < BJ_NROW; ++j) {
+          const int f = tid + j * BJ_INNER_THREADS, Qi = f / BJ_W, i = f % BJ_W;
+          ip[j] = i * BJ_ILD + Qi;
+          iq[j] = i * BJ_ILD + BJ_B + ((Qi + st) & (BJ_B - 1));
+          rq[j] = cs[Qi];
+          vp[j] = Q[ip[j]];
+          vq[j] = Q[iq[j]];
+        }
+#pragma unroll
+        for (int u = 0; u < BJ_NBLK; ++u) {
+          const Blk2 o = bj_block(a11[u], a12[u], a21[u], a22[u], r1[u], r2[u], same[u] && r1[u].s != (real)0);
+          Sw[i11[u]] = o.n11;
+          Sw[i12[u]] = o.n12;
+          Sw[i21[u]] = o.n21;
+          Sw[i22[u]] = o.n22;
+        }
+#pragma unroll
+        for (int j = 0; j < BJ_NROW; ++j) {
+          Q[ip[j]] = fma(rq[j].c, vp[j], -(rq[j].s * vq[j]));
+          Q[iq[j]] = fma(rq[j].s, vp[j], rq[j].c * vq[j]);
+        }
+        if (tid == 0) rotated = 1;
+      }
+    } else if (ahead && st + 1 < nst) {
+      // next step's pair: p' = ai, q' = 32 + (ai + st + 1) mod 32.  In THIS step p' is the first index of pair ai (partner qa), q' the
+      // second index of pair aj = (ai + 1) mod 32 (whose first index is aj)
+      const int aj = (ai + 1) & (BJ_B - 1), qa = BJ_B + ((ai + st) & (BJ_B - 1)), qn = BJ_B + ((ai + st + 1) & (BJ_B - 1));
+      const RotCS ri = cs[ai], rj = cs[aj];
+      if (ai == 0) rot_any[gen ^ 1] = 0; // (read last before the previous step's barrier)
+      // block (ai, ai): rows ai, qa x columns ai, qa -> its n11 is S'[p'][p']
+      const real d11 = Sr[ai * BJ_ILD + ai], d12 = Sr[ai * BJ_ILD + qa], d21 = Sr[qa * BJ_ILD + ai], d22 = Sr[qa * BJ_ILD + qa];
+      // block (aj, aj): rows aj, qn x columns aj, qn -> its n22 is S'[q'][q']
+      const real e11 = Sr[aj * BJ_ILD + aj], e12 = Sr[aj * BJ_ILD + qn], e21 = Sr[qn * BJ_ILD + aj], e22 = Sr[qn * BJ_ILD + qn];
+      // block (ai, aj): rows ai, qa x columns aj, qn -> its n12 is S'[p'][q']
+      const real f11 = Sr[ai * BJ_ILD + aj], f12 = Sr[ai * BJ_ILD + qn], f21 = Sr[qa * BJ_ILD + aj], f22 = Sr[qa * BJ_ILD + qn];
+      const Blk2 bd = bj_block(d11, d12, d21, d22, ri, ri, ri.s != (real)0);
+      const Blk2 be = bj_block(e11, e12, e21, e22, rj, rj, rj.s != (real)0);
+      const Blk2 bf = bj_block(f11, f12, f21, f22, ri, rj, false);
+      __builtin_amdgcn_s_waitcnt(0xc07f); // (lgkmcnt(0): the reset of rot_any above is in LDS before `form` may set it)
+      form(gen ^ 1, qn, bd.n11, be.n22, bf.n12);
+    }
+    __syncthreads();
+    if (any) cur ^= 1;
+  }
+  offmax = block_max(offmax, red); // (contains the barriers that make `rotated` visible)
+  if (tid == 0) {
+    if (offmax > (real)0) atomicMax(&ctl->offmax_bits[offslot], bp_bits(offmax));
+    *flag_out = rotated;
+  }
+  if (!rotated) return; // uniform: nobody reads Q / S' of a pair whose flag is 0
+  const real *Sf = S0 + cur * BJ_W * BJ_ILD;
+  for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
+    const int r = e & (BJ_W - 1), c = e >> 6;
+    Qg[c * BJ_W + r] = Q[r * BJ_ILD + c];
+    Sg[c * BJ_W + r] = Sf[r * BJ_ILD + c];
+  }
+}
+
+__device__ __forceinline__ void bj_inner_sweep(unsigned char *smem, int2 IJ, int kind, int k, real thr, BigPsdCtl *ctl, int offslot, real *Qg,
+                                               real *Sg, int *flag_out) {
+  if (kind == 2) bj_inner_sweep_cross(smem, IJ, k, thr, ctl, offslot, Qg, Sg, flag_out);
+  else if (kind == 1) bj_inner_sweep_k<1>(smem, IJ, k, thr, ctl, offslot, Qg, Sg, flag_out);
+  else bj_inner_sweep_k<0>(smem, IJ, k, thr, ctl, offslot, Qg, Sg, flag_out);
+}
+
+// Qbuf / Sbuf: per (block, pair) 64 x 64 column-major; Qflag: 1 if the sweep rotated anything
+__global__ __launch_bounds__(BJ_INNER_LAUNCH) void k_bj_inner(BigPsdView B, real *Qbuf, real *Sbuf, int *Qflag, int npmax, int arg, int cross) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
+  real *S = reinterpret_cast<real *>(bj_smem);
+  const int slot = arg & 1, step = arg >> 1;
+  const int b = blockIdx.y, pi = blockIdx.x, tid = threadIdx.x;
+  BigPsdCtl *ctl = B.ctl + b;
+  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
+  const real thr = ctl->thr;
+  const BlockShape sh = bp_shape_raw(kraw);
+  if (done || step >= bj_outer_steps(sh.nbc, cross) || pi >= sh.nbc / 2) return;
+  const int2 IJ = bj_pair_sched(pi, step, sh.nbc, cross);
+  const int kind = !cross ? 0 : (step == 0 ? 1 : 2);
+  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
+  const real *Aold = (cur ? B.A1 : B.A) + mat;
+  for (int e = tid; e < BJ_W * BJ_W; e += BJ_INNER_LAUNCH) {
+    const int r = e & (BJ_W - 1), c = e >> 6; // r fast: 32-entry runs of a column of A
+    S[r * BJ_ILD + c] = Aold[(size_t)bj_gidx(IJ, c) * ld + bj_gidx(IJ, r)];
+  }
+  const size_t slot_q = ((size_t)b * npmax + pi);
+  bj_inner_sweep(bj_smem, IJ, kind, sh.k, thr, ctl, ctl->sweeps & 1, Qbuf + slot_q * BJ_W * BJ_W, Sbuf + slot_q * BJ_W * BJ_W, Qflag + slot_q);
 }
 
 #ifndef BJ_UPD_THREADS_OVERRIDE
@@ -445,14 +629,16 @@ constexpr int BJ_UPD_THREADS = 1024; // sixteen waves: one 16 x 16 output tile e
 #else
 constexpr int BJ_UPD_THREADS = BJ_UPD_THREADS_OVERRIDE;
 #endif
-// O[i][j] = sum_k L[i][k] R[k][j] for 64 x 64 operands in LDS: L[i][k] at L[i * BJ_LD + k], R[k][j] at R[j * BJ_LD + k] (both
-// contiguous along the summation index), O[i][j] at O[j * BJ_LD + i].  16 x 16 output tiles dealt to the waves; lane
-// (li = l & 15, lk = l >> 4) supplies L[16 ti + li][4 ks + lk] and R[4 ks + lk][16 tj + li].
-__device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O, int tid) {
+// O[i][j] = sum_k L[i][k] R[k][j] for operands in LDS, 64 summation indices, i < 16 mt, j < 16 nt: L[i][k] at L[i * BJ_LD + k], R[k][j] at
+// R[j * BJ_LD + k] (both contiguous along the summation index), O[i][j] at O[j * BJ_LD + i].  16 x 16 output tiles dealt to the waves;
+// lane (li = l & 15, lk = l >> 4) supplies L[16 ti + li][4 ks + lk] and R[4 ks + lk][16 tj + li].  An output entry is the same sequence of
+// operations whatever mt, nt and the number of waves are (the fused step computes a quarter of a tile product and must get the
+// update's bits).
+__device__ __forceinline__ void bj_gemm_part(const real *L, const real *R, real *O, int mt, int nt, int tid, int nthr) {
 #ifndef SFLOAT
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  for (int t = wave; t < 16; t += BJ_UPD_THREADS / SCSAMD_WAVE) {
-    const int ti = t & 3, tj = t >> 2;
+  for (int t = wave; t < mt * nt; t += nthr / SCSAMD_WAVE) {
+    const int ti = t % mt, tj = t / mt;
     const real *lp = L + (ti * 16 + li) * BJ_LD + lk, *rp = R + (tj * 16 + li) * BJ_LD + lk;
     f64x4 acc = {0, 0, 0, 0};
 #pragma unroll
@@ -461,37 +647,28 @@ __device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O,
     for (int r = 0; r < 4; ++r) O[(tj * 16 + li) * BJ_LD + ti * 16 + lk + 4 * r] = acc[r];
   }
 #else
-  for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
-    const int i = e & (BJ_W - 1), j = e >> 6;
+  for (int e = tid; e < 256 * mt * nt; e += nthr) {
+    const int i = e % (16 * mt), j = e / (16 * mt);
     real acc = 0;
     for (int kk = 0; kk < BJ_W; ++kk) acc += L[i * BJ_LD + kk] * R[j * BJ_LD + kk];
     O[j * BJ_LD + i] = acc;
   }
 #endif
 }
+__device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O, int tid) { bj_gemm_part(L, R, O, 4, 4, tid, BJ_UPD_THREADS); }
 
-__global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
-                                                          const int *__restrict__ Qflag, int npmax, int arg, int cross) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
-  real *xs = reinterpret_cast<real *>(bj_smem);
+// one tile of the step `step` of block b: tile < nta -> A tile (P <= Q) and its mirror, else a V tile.  smem: 4 x 64 x BJ_LD reals.
+__device__ __forceinline__ void bj_update_job(const BigPsdView &B, unsigned char *smem, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
+                                              const int *__restrict__ Qflag, int npmax, int b, int tile, int step, int cross, const BlockShape &sh,
+                                              const real *Aold, real *Anew, real *V) {
+  real *xs = reinterpret_cast<real *>(smem);
   real *qp = xs + BJ_W * BJ_LD, *qq = qp + BJ_W * BJ_LD, *ts = qq + BJ_W * BJ_LD;
-  const int slot = arg & 1, step = arg >> 1;
-  const int b = blockIdx.y, tid = threadIdx.x;
-  BigPsdCtl *ctl = B.ctl + b;
-  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
-  const BlockShape sh = bp_shape_raw(kraw);
-  const bool active = !done && step < bj_outer_steps(sh.nbc, cross);
-  if (blockIdx.x == 0 && tid == 0) ctl->cur[slot ^ 1] = active ? cur ^ 1 : cur;
-  if (!active) return;
-  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
-  const real *Aold = (cur ? B.A1 : B.A) + mat;
-  real *Anew = (cur ? B.A : B.A1) + mat;
-  real *V = B.V + mat;
+  const int tid = threadIdx.x;
+  const size_t ld = B.ld;
   // Only the tiles (P, Q) with P <= Q are computed; the mirror tile (Q, P) receives the transpose, so A stays EXACTLY symmetric
   // from step to step (two independent products Q_P' A[P,Q] Q_Q and Q_Q' A[Q,P] Q_P sum in different orders: symmetric only to
   // rounding, and k_bj_inner builds its rotations from one triangle) and the step does half the matrix-core work.
   const int np = sh.nbc / 2, nta = np * (np + 1) / 2, TR = sh.K64 / BJ_W;
-  int tile = blockIdx.x;
   if (tile >= nta + np * TR) return;
   const int *flags = Qflag + (size_t)b * npmax;
   const real *Qb = Qbuf + (size_t)b * npmax * BJ_W * BJ_W, *Sb = Sbuf + (size_t)b * npmax * BJ_W * BJ_W;
@@ -568,6 +745,151 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
   }
 }
 
+
+__global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
+                                                          const int *__restrict__ Qflag, int npmax, int arg, int cross) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
+  const int slot = arg & 1, step = arg >> 1;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  BigPsdCtl *ctl = B.ctl + b;
+  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[slot];
+  const BlockShape sh = bp_shape_raw(kraw);
+  const bool active = !done && step < bj_outer_steps(sh.nbc, cross);
+  if (blockIdx.x == 0 && tid == 0) ctl->cur[slot ^ 1] = active ? cur ^ 1 : cur;
+  if (!active) return;
+  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
+  bj_update_job(B, bj_smem, Qbuf, Sbuf, Qflag, npmax, b, blockIdx.x, step, cross, sh, (cur ? B.A1 : B.A) + mat, (cur ? B.A : B.A1) + mat, B.V + mat);
+}
+
+// ---- the fused step (round 4; VERDICT r3 item 2: "overlap outer step k+1's k_bj_inner with step k's k_bj_update").
+// The inner sweep is one workgroup per pair of block columns (16 workgroups for a 1024 x 1024 block) and a chain of 32 dependent
+// steps: 40 us in which the rest of the chip idles; the update is 14 us of the whole chip.  As two launches they add up.  This launch
+// does both: workgroups [0, npmax) run the inner sweep of step k + 1, the others the update of step k.  The inner sweep of step k + 1
+// needs A as the update of step k leaves it -- only the 64 x 64 diagonal subproblem of ITS pair (I', J'), which it forms itself from
+// what the update reads (the matrix before step k, Q and S' of step k's pairs): the quadrants [I', I'] and [J', J'] are pieces of the
+// diagonal tiles of step k (S' of the pair the block column was in), the quadrant [I', J'] is a 32 x 32 piece of
+// Q_P' A[P, Q] Q_Q for the two step-k pairs P, Q that held I' and J' -- the same tile product, in the same orientation (P <= Q) and
+// operation order as bj_update_job computes it, so the subproblem has the bits the update writes to the other copy of A.
+// Q / S' / flags are double-buffered by launch (the update of step k reads step k's while the inner sweep writes step k + 1's).
+// The last launch of a sweep runs the FIRST inner sweep of the next sweep before k_bp_sweep_end has closed this one (its
+// off-diagonal maximum goes to the other parity slot of the control record); if the block turns out converged the work is dropped.
+struct BjFusedArgs {
+  int slot;        // launch parity of the control record's `cur` (as `arg & 1` of the two-launch form)
+  int do_update;   // 0: the first launch of a projection (inner sweep of step 0 only)
+  int upd_step;    // outer step the update workgroups apply
+  int inn_step;    // outer step of the inner sweep
+  int next_sweep;  // inner sweep belongs to the sweep after the current one (inn_step == 0 of it)
+  int qin, qout;   // which of the two Q / S' / flag buffers the update reads / the inner sweep writes
+  int cross;
+};
+
+__global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real *Qbuf2, real *Sbuf2, int *Qflag2, int npmax, BjFusedArgs F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  BigPsdCtl *ctl = B.ctl + b;
+  const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[F.slot];
+  const BlockShape sh = bp_shape_raw(kraw);
+  const int ost = bj_outer_steps(sh.nbc, F.cross);
+  const bool upd_active = F.do_update && !done && F.upd_step < ost;
+  const size_t ld = B.ld, mat = (size_t)b * ld * ld;
+  const real *Aold = (cur ? B.A1 : B.A) + mat;
+  const size_t qsz = (size_t)B.nbig * npmax * BJ_W * BJ_W, fsz = (size_t)B.nbig * npmax;
+  const real *Qin = Qbuf2 + F.qin * qsz, *Sin = Sbuf2 + F.qin * qsz;
+  const int *Fin = Qflag2 + F.qin * fsz;
+  if ((int)blockIdx.x >= npmax) { // ---- update of step upd_step
+    if (!F.do_update) return;
+    if ((int)blockIdx.x == npmax && tid == 0) ctl->cur[F.slot ^ 1] = upd_active ? cur ^ 1 : cur;
+    if (!upd_active) return;
+    bj_update_job(B, bj_smem, Qin, Sin, Fin, npmax, b, (int)blockIdx.x - npmax, F.upd_step, F.cross, sh, Aold, (cur ? B.A : B.A1) + mat, B.V + mat);
+    return;
+  }
+  // ---- inner sweep of step inn_step on the matrix as the update of this launch leaves it
+  const int pi = blockIdx.x;
+  if (done || pi >= sh.nbc / 2 || (!F.next_sweep && F.inn_step >= ost)) return;
+  const real thr = ctl->thr;
+  const int2 IJ = bj_pair_sched(pi, F.inn_step, sh.nbc, F.cross);
+  const int kind = !F.cross ? 0 : (F.inn_step == 0 ? 1 : 2);
+  real *S = reinterpret_cast<real *>(bj_smem);
+  const int nthr = BJ_UPD_THREADS;
+  if (!upd_active) { // (a smaller block whose sweep is over, or the first launch) the matrix is not changing under this launch
+    for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
+      const int r = e & (BJ_W - 1), c = e >> 6;
+      S[r * BJ_ILD + c] = Aold[(size_t)bj_gidx(IJ, c) * ld + bj_gidx(IJ, r)];
+    }
+  } else {
+    __shared__ int s_prev[4]; // pair and half (0: it was the pair's I, 1: its J) of I' and of J' in step upd_step
+    const int np = sh.nbc / 2;
+    if (tid < np) {
+      const int2 pr = bj_pair_sched(tid, F.upd_step, sh.nbc, F.cross);
+      if (pr.x == IJ.x || pr.y == IJ.x) { s_prev[0] = tid; s_prev[1] = pr.y == IJ.x; }
+      if (pr.x == IJ.y || pr.y == IJ.y) { s_prev[2] = tid; s_prev[3] = pr.y == IJ.y; }
+    }
+    __syncthreads();
+    const int PI = s_prev[0], hI = s_prev[1], PJ = s_prev[2], hJ = s_prev[3];
+    const int *flags = Fin + (size_t)b * npmax;
+    const real *Qb = Qin + (size_t)b * npmax * BJ_W * BJ_W, *Sb = Sin + (size_t)b * npmax * BJ_W * BJ_W;
+    const int2 prI = bj_pair_sched(PI, F.upd_step, sh.nbc, F.cross), prJ = bj_pair_sched(PJ, F.upd_step, sh.nbc, F.cross);
+    const int fI = flags[PI], fJ = flags[PJ];
+    // entry (hr * 32 + x, hc * 32 + y) of the diagonal tile of step-k pair P after the update: S' of the pair, or A itself if it did not rotate
+    auto diag = [&](int P, int2 pr, int f, int rr, int cc) -> real {
+      return f ? Sb[(size_t)P * BJ_W * BJ_W + cc * BJ_W + rr] : Aold[(size_t)bj_gidx(pr, cc) * ld + bj_gidx(pr, rr)];
+    };
+    for (int e = tid; e < 2 * BJ_B * BJ_B; e += nthr) { // quadrants [I', I'] and [J', J']
+      const int x = e & (BJ_B - 1), y = (e >> 5) & (BJ_B - 1), which = e >> 10;
+      if (which == 0) S[x * BJ_ILD + y] = diag(PI, prI, fI, hI * BJ_B + x, hI * BJ_B + y);
+      else S[(BJ_B + x) * BJ_ILD + BJ_B + y] = diag(PJ, prJ, fJ, hJ * BJ_B + x, hJ * BJ_B + y);
+    }
+    if (PI == PJ) { // I' and J' sat in ONE pair of step k: the quadrant is a piece of that pair's diagonal tile too
+      for (int e = tid; e < BJ_B * BJ_B; e += nthr) {
+        const int x = e & (BJ_B - 1), y = e >> 5;
+        const real v = diag(PI, prI, fI, hI * BJ_B + x, hJ * BJ_B + y);
+        S[x * BJ_ILD + BJ_B + y] = v;
+        S[(BJ_B + y) * BJ_ILD + x] = v;
+      }
+    } else if (!fI && !fJ) { // neither pair rotated: the update copies the tile
+      for (int e = tid; e < BJ_B * BJ_B; e += nthr) {
+        const int x = e & (BJ_B - 1), y = e >> 5;
+        const real v = Aold[(size_t)bj_gidx(IJ, BJ_B + y) * ld + bj_gidx(IJ, x)];
+        S[x * BJ_ILD + BJ_B + y] = v;
+        S[(BJ_B + y) * BJ_ILD + x] = v;
+      }
+    } else {
+      // the tile (Pa <= Pb) as bj_update_job forms it: O = Q_Pa' A[Pa, Pb] Q_Pb, of which the rows of half ha and the columns of half hb
+      const bool swap = PI > PJ;
+      const int Pa = swap ? PJ : PI, Pb = swap ? PI : PJ, ha = swap ? hJ : hI, hb = swap ? hI : hJ, fa = swap ? fJ : fI, fb = swap ? fI : fJ;
+      const int2 pra = swap ? prJ : prI, prb = swap ? prI : prJ;
+      real *xs = S + BJ_W * BJ_ILD; // scratch behind S, over its second copy, Q and the rotation tables (which the sweep sets up afterwards): ends at 134 656 B
+      static_assert((size_t)(BJ_W * BJ_ILD + BJ_W * BJ_LD + 4 * BJ_B * BJ_LD) * sizeof(real) <= BJ_UPDATE_LDS, "k_bj_fused: prologue scratch");
+      real *qq = xs + BJ_W * BJ_LD, *qp = qq + BJ_B * BJ_LD, *ts = qp + BJ_B * BJ_LD, *out = ts + BJ_B * BJ_LD;
+      for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
+        const int i = e & (BJ_W - 1), kk = e >> 6;
+        xs[i * BJ_LD + kk] = Aold[(size_t)bj_gidx(prb, kk) * ld + bj_gidx(pra, i)];
+      }
+      for (int e = tid; e < BJ_W * BJ_B; e += nthr) { // 32 columns of each Q (identity where the pair did not rotate)
+        const int i = e & (BJ_W - 1), j = e >> 6;
+        qq[j * BJ_LD + i] = fb ? Qb[(size_t)Pb * BJ_W * BJ_W + (hb * BJ_B + j) * BJ_W + i] : (i == hb * BJ_B + j ? (real)1 : (real)0);
+        qp[j * BJ_LD + i] = fa ? Qb[(size_t)Pa * BJ_W * BJ_W + (ha * BJ_B + j) * BJ_W + i] : (i == ha * BJ_B + j ? (real)1 : (real)0);
+      }
+      __syncthreads();
+      bj_gemm_part(xs, qq, ts, 4, 2, tid, nthr);  // T[:, hb half] = X Q_Pb[:, hb half]
+      __syncthreads();
+      bj_gemm_part(qp, ts, out, 2, 2, tid, nthr); // O[ha half, hb half] = Q_Pa[:, ha half]' T
+      __syncthreads();
+      for (int e = tid; e < BJ_B * BJ_B; e += nthr) {
+        const int i = e & (BJ_B - 1), j = e >> 5; // O[i][j] at out[j * BJ_LD + i]: row i of half ha, column j of half hb
+        const real v = out[j * BJ_LD + i];
+        const int x = swap ? j : i, y = swap ? i : j; // x: index in I', y: index in J'
+        S[x * BJ_ILD + BJ_B + y] = v;
+        S[(BJ_B + y) * BJ_ILD + x] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const size_t slot_q = (size_t)b * npmax + pi;
+  bj_inner_sweep(bj_smem, IJ, kind, sh.k, thr, ctl, (ctl->sweeps + (F.next_sweep ? 1 : 0)) & 1, Qbuf2 + F.qout * qsz + slot_q * BJ_W * BJ_W,
+                 Sbuf2 + F.qout * qsz + slot_q * BJ_W * BJ_W, Qflag2 + F.qout * fsz + slot_q);
+}
+
 // closes a sweep for every block; *remaining = blocks still iterating
 __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -576,8 +898,9 @@ __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
     BigPsdCtl *c = B.ctl + b;
     if (c->done) continue;
     worked = 1;
+    const int par = c->sweeps & 1;
     c->sweeps += 1;
-    if (bp_from_bits(c->offmax_bits) <= c->thr) {
+    if (bp_from_bits(c->offmax_bits[par]) <= c->thr) {
       c->done = 1;
     } else if (c->sweeps >= PSD_MAX_SWEEPS) {
       c->done = 1;
@@ -585,7 +908,7 @@ __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
     } else {
       ++rem;
     }
-    c->offmax_bits = 0ull;
+    c->offmax_bits[par] = 0ull;
   }
   remaining[0] = rem;
   remaining[1] += worked; // sweeps of this projection in which some block still iterated (the host sizes its next batch from it)
@@ -769,6 +1092,7 @@ struct BigPsd {
   bool blocked = true;       // tournament over 32-wide block columns with MFMA updates (k_bj_*); false: single columns (k_bp_step)
   int sweeps_hint[2] = {0, 0}; // sweeps the previous projection of the same kind ([0] cold start, [1] warm start) needed: that many minus one
                              // are enqueued before the first read-back (a cold projection's ~10 must not size the next warm one's batch)
+  bool fused = true;         // blocked: one launch per outer step (k_bj_fused) instead of k_bj_inner + k_bj_update
   bool cross = true;         // blocked: every index pair once per sweep (within pass + cross-pair tournament steps), see bj_pair_sched
   DevBuf<real> Qbuf, Sbuf;   // blocked: per (block, block-column pair) the 64 x 64 factor Q and rotated subproblem S'
   DevBuf<int> Qflag;         // ... and whether the pair's inner sweep rotated at all
@@ -794,9 +1118,12 @@ struct BigPsd {
     if (const char *e = getenv("SCS_AMD_PSD_CROSS")) cross = atoi(e) != 0; // 0: full 63-step sweeps of every block-column pair (first form of round 3)
     if (blocked) {
       const size_t npmax = (size_t)ld / BJ_W;
-      Qbuf.alloc((size_t)nbig * npmax * BJ_W * BJ_W);
-      Sbuf.alloc((size_t)nbig * npmax * BJ_W * BJ_W);
-      Qflag.alloc((size_t)nbig * npmax);
+      fused = true;
+      if (const char *e = getenv("SCS_AMD_PSD_FUSED")) fused = atoi(e) != 0; // 0: inner sweep and update as two launches per outer step (A/B measurements)
+      Qbuf.alloc((size_t)2 * nbig * npmax * BJ_W * BJ_W); // two generations (k_bj_fused)
+      Sbuf.alloc((size_t)2 * nbig * npmax * BJ_W * BJ_W);
+      Qflag.alloc((size_t)2 * nbig * npmax);
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bj_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BJ_UPDATE_LDS));
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bj_inner), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BJ_INNER_LDS));
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bj_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BJ_UPDATE_LDS));
     }
@@ -839,6 +1166,8 @@ struct BigPsd {
     }
     hipLaunchKernelGGL(k_bp_norm, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B);
     int h_rem[2] = {nbig, 0};
+    long long qgen = 0;  // fused step: generations of Q / S' / flags written so far
+    bool first_launch = true;
     long long gstep = 0; // launches so far: the copy of A a block is in alternates with the steps IT took (ctl.cur)
     const long long sweeps_before = sweeps_total;
     const int nbc_max = ld / BJ_B, npmax = ld / BJ_W;
@@ -852,9 +1181,24 @@ struct BigPsd {
      for (int bsw = 0; bsw < batch; ++bsw, ++enq) {
       if (blocked) {
         const int osteps = cross ? nbc_max : nbc_max - 1; // cross schedule: the within pass, then the tournament steps
+        if (fused) {
+          const int g_fused = npmax + g_upd;
+          for (int step = 0; step < osteps; ++step, ++gstep) {
+            if (first_launch) { // inner sweep of step 0 of the first sweep; nothing to update yet
+              const BjFusedArgs F0{(int)(gstep & 1), 0, 0, 0, 0, 0, (int)(qgen & 1), cross ? 1 : 0};
+              hipLaunchKernelGGL(k_bj_fused, dim3(npmax, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F0);
+              ++qgen;
+              first_launch = false;
+            }
+            const bool last = step + 1 == osteps;
+            const BjFusedArgs F{(int)(gstep & 1), 1, step, last ? 0 : step + 1, last ? 1 : 0, (int)((qgen - 1) & 1), (int)(qgen & 1), cross ? 1 : 0};
+            hipLaunchKernelGGL(k_bj_fused, dim3(g_fused, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F);
+            ++qgen;
+          }
+        } else
         for (int step = 0; step < osteps; ++step, ++gstep) {
           const int arg = (int)(gstep & 1) | (step << 1);
-          hipLaunchKernelGGL(k_bj_inner, dim3(npmax, nbig), dim3(BJ_INNER_THREADS), BJ_INNER_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, arg,
+          hipLaunchKernelGGL(k_bj_inner, dim3(npmax, nbig), dim3(BJ_INNER_LAUNCH), BJ_INNER_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, arg,
                              cross ? 1 : 0);
           hipLaunchKernelGGL(k_bj_update, dim3(g_upd, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, (const real *)Qbuf.p,
                              (const real *)Sbuf.p, (const int *)Qflag.p, npmax, arg, cross ? 1 : 0);
