@@ -342,7 +342,7 @@ __device__ __forceinline__ void bj_inner_sweep_k(unsigned char *smem, int2 IJ, i
   real *Q = S + 2 * BJ_W * BJ_ILD; // (the second copy of S between them is the cross sweep's)
   RotCS *rot_cs = reinterpret_cast<RotCS *>(Q + BJ_W * BJ_ILD);
   __shared__ real red[BJ_UPD_THREADS_MAX / SCSAMD_WAVE];
-  __shared__ volatile int rot_any[2];
+  __shared__ int rot_any[2]; // (plain LDS accesses; a volatile flag is reached through FLAT loads / stores with system scope)
   __shared__ int rotated;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const bool worker = tid < BJ_INNER_THREADS;
@@ -351,7 +351,6 @@ __device__ __forceinline__ void bj_inner_sweep_k(unsigned char *smem, int2 IJ, i
     const int r = e & (BJ_W - 1), c = e >> 6;
     Q[r * BJ_ILD + c] = r == c ? (real)1 : (real)0;
   }
-  if (tid < 2) rot_any[tid] = 0;
   if (tid == 0) rotated = 0;
   __syncthreads();
   real offmax = 0;
@@ -367,15 +366,14 @@ __device__ __forceinline__ void bj_inner_sweep_k(unsigned char *smem, int2 IJ, i
       const real aa = absval(apq);
       const bool real_pair = bj_gidx(IJ, q) < k; // local order = global order (I < J): q is the larger index
       if (real_pair) offmax = aa > offmax ? aa : offmax;
-      if (real_pair && aa > thr) {
-        jacobi_cs(aqq - app, (real)2 * apq, c, s);
-        rot_any[par] = 1;
-      }
+      const bool rot = real_pair && aa > thr;
+      if (rot) jacobi_cs(aqq - app, (real)2 * apq, c, s);
       rot_cs[i] = RotCS{c, s};
-      if (i == 0) rot_any[par ^ 1] = 0;
+      const int vote = __any(rot ? 1 : 0); // the 32 lanes are half of one wave
+      if (i == 0) rot_any[par] = vote;
     }
     __syncthreads();
-    const int any = rot_any[par]; // uniform over the workgroup (nobody sets this parity again before the next step's barrier)
+    const int any = rot_any[par]; // uniform over the workgroup (this parity is written again two steps on, behind the next step's barrier)
     if (worker) {
       int i11[BJ_NBLK], i12[BJ_NBLK], i21[BJ_NBLK], i22[BJ_NBLK], ip[BJ_NROW], iq[BJ_NROW];
       RotCS r1[BJ_NBLK], r2[BJ_NBLK], rq[BJ_NROW];
@@ -442,6 +440,19 @@ __device__ __forceinline__ void bj_inner_sweep_k(unsigned char *smem, int2 IJ, i
     Sg[c * BJ_W + r] = S[r * BJ_ILD + c];
   }
 }
+// (measurement knobs of the cross sweep; the defaults are what ships)
+#ifndef BJ_AHEAD_PRIO
+#define BJ_AHEAD_PRIO 3
+#endif
+#ifndef BJ_AHEAD_ONE_BATCH
+#define BJ_AHEAD_ONE_BATCH 1
+#endif
+#ifndef BJ_AHEAD_ANY_LATE
+#define BJ_AHEAD_ANY_LATE 1
+#endif
+#ifndef BJ_WORKER_SLEEP
+#define BJ_WORKER_SLEEP 0
+#endif
 // one 2x2 block of J' S J: rows rotated by (c1, s1), then columns by (c2, s2); `own`: the block of a rotated pair with itself, whose
 // off-diagonal entries are exact zeros.  ONE definition (explicit fused multiply-adds) for the lanes that update S and the lanes that
 // look one step ahead, so that both get the same bits.
@@ -474,46 +485,70 @@ __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 I
   real *Q = S0 + 2 * BJ_W * BJ_ILD;
   RotCS *rot_cs = reinterpret_cast<RotCS *>(Q + BJ_W * BJ_ILD); // [2][BJ_B]: generation st & 1 holds the rotations of step st
   __shared__ real red[BJ_UPD_THREADS_MAX / SCSAMD_WAVE];
-  __shared__ volatile int rot_any[2];
+  __shared__ int rot_any[2]; // generation st & 1: does step st rotate anything?  (plain LDS accesses: as a volatile array captured by a
+                             // lambda it was reached through FLAT loads and stores, ~600 clocks at the head of every step)
   __shared__ int rotated;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const bool worker = tid < BJ_INNER_THREADS;
-  const bool ahead = tid >= BJ_INNER_THREADS && tid < BJ_INNER_THREADS + BJ_B; // the 32 lanes that form the rotations
-  const int ai = tid - BJ_INNER_THREADS;                                        // their pair
+  const bool ahead = tid >= BJ_INNER_THREADS && tid < BJ_INNER_THREADS + SCSAMD_WAVE; // the wave that forms the rotations (its two halves do
+  const int ai = (tid - BJ_INNER_THREADS) & (BJ_B - 1);                               // the same work: no divergence; the lanes vote); its pair
   constexpr int NP = BJ_B, nst = BJ_B;
   for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
     const int r = e & (BJ_W - 1), c = e >> 6;
     Q[r * BJ_ILD + c] = r == c ? (real)1 : (real)0;
   }
-  if (tid < 2) rot_any[tid] = 0;
   if (tid == 0) rotated = 0;
   __syncthreads();
   real offmax = 0;
-  // the rotation of pair (p, q) from its three entries; records it as generation `gen`
-  auto form = [&](int gen, int q, real app, real aqq, real apq) {
-    real c = 1, s = 0;
-    const real aa = absval(apq);
-    const bool real_pair = bj_gidx(IJ, q) < k; // local order = global order (I < J): q is the larger index
-    if (real_pair) offmax = aa > offmax ? aa : offmax;
-    if (real_pair && aa > thr) {
-      jacobi_cs(aqq - app, (real)2 * apq, c, s);
-      rot_any[gen] = 1;
-    }
-    rot_cs[gen * BJ_B + ai] = RotCS{c, s};
+  // the rotation of pair (ai, q) from its three entries, recorded as generation `gen`; the 32 lanes vote on "anything to rotate"
+#define BJ_FORM(gen_, q_, app_, aqq_, apq_)                                                                 \
+  do {                                                                                                      \
+    real c_ = 1, s_ = 0;                                                                                    \
+    const real apq__ = (apq_), aa_ = absval(apq__);                                                         \
+    const bool real_pair_ = bj_gidx(IJ, (q_)) < k; /* local order = global order (I < J): q is the larger */ \
+    if (real_pair_) offmax = aa_ > offmax ? aa_ : offmax;                                                   \
+    const bool rot_ = real_pair_ && aa_ > thr;                                                              \
+    if (rot_) jacobi_cs((aqq_) - (app_), (real)2 * apq__, c_, s_);                                          \
+    rot_cs[(gen_) * BJ_B + ai] = RotCS{c_, s_};                                                             \
+    const int vote_ = __any(rot_ ? 1 : 0);                                                                  \
+    if (ai == 0) rot_any[(gen_)] = vote_;                                                                   \
+  } while (0)
+  int ao[12];
+  const int aj = (ai + 1) & (BJ_B - 1);
+  auto ahead_offsets = [&](int st) { // the entries the look-ahead lane reads in step st
+    const int qa = BJ_B + ((ai + st) & (BJ_B - 1)), qn = BJ_B + ((ai + st + 1) & (BJ_B - 1));
+    ao[0] = ai * BJ_ILD + ai, ao[1] = ai * BJ_ILD + qa, ao[2] = qa * BJ_ILD + ai, ao[3] = qa * BJ_ILD + qa;
+    ao[4] = aj * BJ_ILD + aj, ao[5] = aj * BJ_ILD + qn, ao[6] = qn * BJ_ILD + aj, ao[7] = qn * BJ_ILD + qn;
+    ao[8] = ai * BJ_ILD + aj, ao[9] = ai * BJ_ILD + qn, ao[10] = qa * BJ_ILD + aj, ao[11] = qa * BJ_ILD + qn;
   };
   if (ahead) { // step 0's rotations from the matrix as loaded
     const int p = ai, q = BJ_B + ai;
-    form(0, q, S0[p * BJ_ILD + p], S0[q * BJ_ILD + q], S0[p * BJ_ILD + q]);
+    BJ_FORM(0, q, S0[p * BJ_ILD + p], S0[q * BJ_ILD + q], S0[p * BJ_ILD + q]);
+    ahead_offsets(0);
   }
   __syncthreads();
+  // the look-ahead chain (14 LDS reads, 18 + ~40 dependent fp64 instructions) shares its SIMD and the LDS queue with worker waves that
+  // always have something to issue: it goes first (measured without the priority: 1990 clocks per step for the chain, the workers
+  // done after 1370)
+  if (BJ_AHEAD_PRIO && tid >= BJ_INNER_THREADS && tid < BJ_INNER_THREADS + SCSAMD_WAVE) __builtin_amdgcn_s_setprio(BJ_AHEAD_PRIO);
   int cur = 0;
   for (int st = 0; st < nst; ++st) {
     const int gen = st & 1;
     const real *Sr = S0 + cur * BJ_W * BJ_ILD;
     real *Sw = S0 + (cur ^ 1) * BJ_W * BJ_ILD;
     const RotCS *cs = rot_cs + gen * BJ_B;
-    const int any = rot_any[gen]; // uniform (set before the barrier that ended the previous step)
+    int any; // does this step rotate anything?  Uniform (set before the barrier that ended the previous step).  The look-ahead wave asks
+             // for it BEHIND its operand reads: those are the step's first LDS requests, ahead of the workers' 192
+#if !BJ_AHEAD_ANY_LATE
+    any = rot_any[gen];
+#endif
     if (worker) {
+#if BJ_AHEAD_ANY_LATE
+      any = rot_any[gen];
+#endif
+#if BJ_WORKER_SLEEP
+      __builtin_amdgcn_s_sleep(BJ_WORKER_SLEEP);
+#endif
       if (any) { // a step in which no pair is above the threshold changes nothing
         int i11[BJ_NBLK], i12[BJ_NBLK], i21[BJ_NBLK], i22[BJ_NBLK], ip[BJ_NROW], iq[BJ_NROW];
         RotCS r1[BJ_NBLK], r2[BJ_NBLK], rq[BJ_NROW];
@@ -561,21 +596,30 @@ __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 I
       }
     } else if (ahead && st + 1 < nst) {
       // next step's pair: p' = ai, q' = 32 + (ai + st + 1) mod 32.  In THIS step p' is the first index of pair ai (partner qa), q' the
-      // second index of pair aj = (ai + 1) mod 32 (whose first index is aj)
-      const int aj = (ai + 1) & (BJ_B - 1), qa = BJ_B + ((ai + st) & (BJ_B - 1)), qn = BJ_B + ((ai + st + 1) & (BJ_B - 1));
+      // second index of pair aj = (ai + 1) mod 32 (whose first index is aj).  The twelve offsets were formed before the barrier: the
+      // reads below are this wave's first instructions of the step and enter the LDS queue ahead of the workers' 192 (behind them they
+      // came back after 1340 clocks)
+      const real d11 = Sr[ao[0]], d12 = Sr[ao[1]], d21 = Sr[ao[2]], d22 = Sr[ao[3]];     // block (ai, ai): its n11 is S'[p'][p']
+      const real e11 = Sr[ao[4]], e12 = Sr[ao[5]], e21 = Sr[ao[6]], e22 = Sr[ao[7]];     // block (aj, aj): its n22 is S'[q'][q']
+      const real f11 = Sr[ao[8]], f12 = Sr[ao[9]], f21 = Sr[ao[10]], f22 = Sr[ao[11]];   // block (ai, aj): its n12 is S'[p'][q']
       const RotCS ri = cs[ai], rj = cs[aj];
-      if (ai == 0) rot_any[gen ^ 1] = 0; // (read last before the previous step's barrier)
-      // block (ai, ai): rows ai, qa x columns ai, qa -> its n11 is S'[p'][p']
-      const real d11 = Sr[ai * BJ_ILD + ai], d12 = Sr[ai * BJ_ILD + qa], d21 = Sr[qa * BJ_ILD + ai], d22 = Sr[qa * BJ_ILD + qa];
-      // block (aj, aj): rows aj, qn x columns aj, qn -> its n22 is S'[q'][q']
-      const real e11 = Sr[aj * BJ_ILD + aj], e12 = Sr[aj * BJ_ILD + qn], e21 = Sr[qn * BJ_ILD + aj], e22 = Sr[qn * BJ_ILD + qn];
-      // block (ai, aj): rows ai, qa x columns aj, qn -> its n12 is S'[p'][q']
-      const real f11 = Sr[ai * BJ_ILD + aj], f12 = Sr[ai * BJ_ILD + qn], f21 = Sr[qa * BJ_ILD + aj], f22 = Sr[qa * BJ_ILD + qn];
+#if BJ_AHEAD_ANY_LATE
+      any = rot_any[gen];
+#endif
+#if BJ_AHEAD_ONE_BATCH
+      __builtin_amdgcn_sched_barrier(0); // all fourteen reads in ONE round trip (the scheduler had split them into three, each queueing
+                                         // behind the workers' traffic: 1340 clocks before the last operand arrived)
+#endif
+      const int qn = BJ_B + ((ai + st + 1) & (BJ_B - 1));
       const Blk2 bd = bj_block(d11, d12, d21, d22, ri, ri, ri.s != (real)0);
       const Blk2 be = bj_block(e11, e12, e21, e22, rj, rj, rj.s != (real)0);
       const Blk2 bf = bj_block(f11, f12, f21, f22, ri, rj, false);
-      __builtin_amdgcn_s_waitcnt(0xc07f); // (lgkmcnt(0): the reset of rot_any above is in LDS before `form` may set it)
-      form(gen ^ 1, qn, bd.n11, be.n22, bf.n12);
+      BJ_FORM(gen ^ 1, qn, bd.n11, be.n22, bf.n12);
+      ahead_offsets(st + 1);
+    } else {
+#if BJ_AHEAD_ANY_LATE
+      any = rot_any[gen];
+#endif
     }
     __syncthreads();
     if (any) cur ^= 1;
