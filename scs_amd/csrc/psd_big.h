@@ -264,7 +264,7 @@ constexpr int BJ_NBLK = BJ_B * BJ_B / BJ_INNER_THREADS; // 2x2 blocks of S per l
 constexpr int BJ_NROW = BJ_W * BJ_B / BJ_INNER_THREADS; // row pairs of Q per lane and inner step
 static_assert(BJ_NBLK * BJ_INNER_THREADS == BJ_B * BJ_B && BJ_NROW * BJ_INNER_THREADS == BJ_W * BJ_B, "k_bj_inner: whole items per lane");
 constexpr size_t BJ_INNER_LDS = (size_t)3 * BJ_W * BJ_ILD * sizeof(real) + 2 * BJ_B * sizeof(RotCS); // S (two copies), Q, two generations of (c, s)
-constexpr int BJ_INNER_LAUNCH = BJ_INNER_THREADS + SCSAMD_WAVE;                                         // the workers and the wave that forms the rotations
+constexpr int BJ_INNER_LAUNCH = 1024; // (= BJ_UPD_THREADS_MAX) the cross sweep's workgroup: fifteen worker waves and the wave that forms the rotations
 constexpr size_t BJ_UPDATE_LDS = (size_t)4 * BJ_W * BJ_LD * sizeof(real);
 
 __device__ __forceinline__ int2 bj_pair(int i, int step, int nbc) { // round robin over block columns, as over columns
@@ -450,9 +450,6 @@ __device__ __forceinline__ void bj_inner_sweep_k(unsigned char *smem, int2 IJ, i
 #ifndef BJ_AHEAD_ANY_LATE
 #define BJ_AHEAD_ANY_LATE 1
 #endif
-#ifndef BJ_WORKER_SLEEP
-#define BJ_WORKER_SLEEP 0
-#endif
 // one 2x2 block of J' S J: rows rotated by (c1, s1), then columns by (c2, s2); `own`: the block of a rotated pair with itself, whose
 // off-diagonal entries are exact zeros.  ONE definition (explicit fused multiply-adds) for the lanes that update S and the lanes that
 // look one step ahead, so that both get the same bits.
@@ -470,31 +467,54 @@ __device__ __forceinline__ Blk2 bj_block(real a11, real a12, real a21, real a22,
   return o;
 }
 
-// The CROSS sweep (pairs p in I, q in J; 32 steps; 31 of the 32 launches of a sweep of a 1024 x 1024 block), software-pipelined: the
-// clocks of the two-phase step above are 910 (rotations: 32 lanes, an LDS round trip, the rsqrt chain, a barrier) + 2020 (update:
-// bound by the vector ALUs' instruction issue, ~150 instructions per wave and step of which 48 are the fp64 arithmetic, and a barrier)
-// (profiles/r4_psd_inner_phases.md).  Here the rotations of step st + 1 are formed DURING the update of step st, by a wave that does
-// nothing else: S is double-buffered (the update reads one copy and writes the other), so the look-ahead lanes can read the old
-// entries while they are being replaced, and apply the current step's rotations to just the three entries their next pair needs
-// (S[p'][p'], S[q'][q'], S[p'][q']: three 2x2 blocks, the same bj_block as the update, hence the same bits).  One barrier per step.
-// Round 3 measured this form slower (114 vs 96 us per sweep): the look-ahead chain then went through pair tables and an fp64
-// sqrt / div / rsqrt sequence and was longer than the update; with arithmetic pairs and the two-rsqrt jacobi_cs it is shorter.
+// The CROSS sweep (pairs p in I, q in J; 32 steps; 31 of the 32 launches of a sweep of a 1024 x 1024 block).  Three things set it apart
+// from the generic sweep above (measurements: profiles/r4_psd_fused_step.md):
+//  * software pipeline: the rotations of step st + 1 are formed DURING the update of step st by a wave that does nothing else (the
+//    two-phase step is 910 clocks of rotations -- an LDS round trip, the rsqrt chain, a barrier -- plus 2020 of update).  S is double-
+//    buffered (the update reads one copy and writes the other), so the look-ahead lanes can read the old entries while they are being
+//    replaced and apply the current step's rotations to just the three entries their next pair needs (S[p'][p'], S[q'][q'], S[p'][q']:
+//    three 2x2 blocks, the same bj_block as the update, hence the same bits).  One barrier per step.  Round 3 measured this form slower
+//    (114 vs 96 us per sweep): the look-ahead chain then went through pair tables and an fp64 sqrt / div / rsqrt sequence.
+//  * the update is bound by LDS throughput (192 wave reads in 690 clocks = the 128 B / clock of the LDS, the same again for the stores),
+//    so it moves less: only the UPPER triangle of the symmetric S is kept (r <= c in local order; 496 off-diagonal 2x2 blocks P < Q and
+//    32 diagonal ones instead of 1024 blocks), and the I column of every (row, pair) item of Q never leaves its lane's registers (a
+//    lane keeps its items for the whole sweep; only the J columns, which change partner every step, live in LDS).  5280 + 6144 LDS
+//    accesses per step instead of 20480, two thirds of the arithmetic.
+//  * waves 0-7 carry the update (a block of S and four items of Q per lane; the arithmetic is a quarter of a wave's instructions, so
+//    fewer waves with more items each beat fifteen waves with one or two), wave 15 looks ahead, the others only keep the barriers company.
 __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 IJ, int k, real thr, BigPsdCtl *ctl, int offslot, real *Qg, real *Sg,
                                                      int *flag_out) {
   real *S0 = reinterpret_cast<real *>(smem);
-  real *Q = S0 + 2 * BJ_W * BJ_ILD;
+  real *Q = S0 + 2 * BJ_W * BJ_ILD;                              // only its J columns (32 .. 63) are used here
   RotCS *rot_cs = reinterpret_cast<RotCS *>(Q + BJ_W * BJ_ILD); // [2][BJ_B]: generation st & 1 holds the rotations of step st
   __shared__ real red[BJ_UPD_THREADS_MAX / SCSAMD_WAVE];
-  __shared__ int rot_any[2]; // generation st & 1: does step st rotate anything?  (plain LDS accesses: as a volatile array captured by a
-                             // lambda it was reached through FLAT loads and stores, ~600 clocks at the head of every step)
+  __shared__ int rot_any[2]; // generation st & 1: does step st rotate anything?
   __shared__ int rotated;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const bool worker = tid < BJ_INNER_THREADS;
-  const bool ahead = tid >= BJ_INNER_THREADS && tid < BJ_INNER_THREADS + SCSAMD_WAVE; // the wave that forms the rotations (its two halves do
-  const int ai = (tid - BJ_INNER_THREADS) & (BJ_B - 1);                               // the same work: no divergence; the lanes vote); its pair
-  constexpr int NP = BJ_B, nst = BJ_B;
-  for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
-    const int r = e & (BJ_W - 1), c = e >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x; // nthr == BJ_UPD_THREADS_MAX
+  constexpr int nst = BJ_B;
+  constexpr int AHEAD0 = BJ_UPD_THREADS_MAX - SCSAMD_WAVE, NOFF = BJ_B * (BJ_B - 1) / 2;
+  const bool ahead = tid >= AHEAD0;       // the wave that forms the rotations (its two halves do the same work: no divergence; the lanes vote)
+  const int ai = (tid - AHEAD0) & (BJ_B - 1), aj = (ai + 1) & (BJ_B - 1);
+  // ---- this lane's items, fixed for the sweep.  Waves 0-7: one block of S (lanes 0 .. 495 the off-diagonal blocks P < Q, lanes 496 .. 511
+  // the diagonal blocks 0 .. 15) and four (row, pair) items of Q; wave 8, lanes 0 .. 15: the diagonal blocks 16 .. 31.
+  const bool qworker = tid < BJ_INNER_THREADS;
+  int sP = -1, sQ = -1; // block of S: rows {sP, q(sP)} x columns {sQ, q(sQ)}, sP <= sQ (q(i) = 32 + (i + st) mod 32)
+  if (tid < NOFF) {     // t -> (P < Q): column Q of the strict upper triangle holds Q blocks
+    int Qc = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)tid)) * 0.5f);
+    while (Qc * (Qc - 1) / 2 > tid) --Qc;
+    while ((Qc + 1) * Qc / 2 <= tid) ++Qc;
+    sQ = Qc;
+    sP = tid - Qc * (Qc - 1) / 2;
+  } else if (tid < NOFF + BJ_B) {
+    sP = sQ = tid - NOFF;
+  }
+  const bool sworker = sP >= 0, diag = sP == sQ;
+  const int qrow = tid & (BJ_W - 1), qpair0 = (tid >> 6) & 7; // items of Q: row qrow, pairs qpair0 + 8 j
+  real qI[4]; // Q[row][pair's I column]: stays here
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qI[j] = qrow == qpair0 + 8 * j ? (real)1 : (real)0;
+  for (int e = tid; e < BJ_W * BJ_B; e += nthr) { // J columns of Q <- those of the identity
+    const int r = e & (BJ_W - 1), c = BJ_B + (e >> 6);
     Q[r * BJ_ILD + c] = r == c ? (real)1 : (real)0;
   }
   if (tid == 0) rotated = 0;
@@ -513,13 +533,18 @@ __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 I
     const int vote_ = __any(rot_ ? 1 : 0);                                                                  \
     if (ai == 0) rot_any[(gen_)] = vote_;                                                                   \
   } while (0)
-  int ao[12];
-  const int aj = (ai + 1) & (BJ_B - 1);
-  auto ahead_offsets = [&](int st) { // the entries the look-ahead lane reads in step st
+  // offsets of the ten entries the look-ahead lane reads in step st.  Next step's pair is p' = ai, q' = qn = 32 + (ai + st + 1) mod 32;
+  // in step st p' is the first index of pair ai (partner qa) and q' the second index of pair aj = (ai + 1) mod 32.
+  //   diagonal block (ai, ai): its n11 is S'[p'][p'];  diagonal block (aj, aj): its n22 is S'[q'][q'];
+  //   block (min, max of ai, aj): its n12 (ai < aj) or n21 (ai = 31, aj = 0) is S'[p'][q']
+  int ao[10];
+  const int fP = ai < aj ? ai : aj, fQ = ai < aj ? aj : ai;
+  auto ahead_offsets = [&](int st) {
     const int qa = BJ_B + ((ai + st) & (BJ_B - 1)), qn = BJ_B + ((ai + st + 1) & (BJ_B - 1));
-    ao[0] = ai * BJ_ILD + ai, ao[1] = ai * BJ_ILD + qa, ao[2] = qa * BJ_ILD + ai, ao[3] = qa * BJ_ILD + qa;
-    ao[4] = aj * BJ_ILD + aj, ao[5] = aj * BJ_ILD + qn, ao[6] = qn * BJ_ILD + aj, ao[7] = qn * BJ_ILD + qn;
-    ao[8] = ai * BJ_ILD + aj, ao[9] = ai * BJ_ILD + qn, ao[10] = qa * BJ_ILD + aj, ao[11] = qa * BJ_ILD + qn;
+    const int qP = ai < aj ? qa : qn, qQ = ai < aj ? qn : qa, lo = qP < qQ ? qP : qQ, hi = qP < qQ ? qQ : qP;
+    ao[0] = ai * BJ_ILD + ai, ao[1] = ai * BJ_ILD + qa, ao[2] = qa * BJ_ILD + qa;
+    ao[3] = aj * BJ_ILD + aj, ao[4] = aj * BJ_ILD + qn, ao[5] = qn * BJ_ILD + qn;
+    ao[6] = fP * BJ_ILD + fQ, ao[7] = fP * BJ_ILD + qQ, ao[8] = fQ * BJ_ILD + qP, ao[9] = lo * BJ_ILD + hi;
   };
   if (ahead) { // step 0's rotations from the matrix as loaded
     const int p = ai, q = BJ_B + ai;
@@ -527,10 +552,7 @@ __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 I
     ahead_offsets(0);
   }
   __syncthreads();
-  // the look-ahead chain (14 LDS reads, 18 + ~40 dependent fp64 instructions) shares its SIMD and the LDS queue with worker waves that
-  // always have something to issue: it goes first (measured without the priority: 1990 clocks per step for the chain, the workers
-  // done after 1370)
-  if (BJ_AHEAD_PRIO && tid >= BJ_INNER_THREADS && tid < BJ_INNER_THREADS + SCSAMD_WAVE) __builtin_amdgcn_s_setprio(BJ_AHEAD_PRIO);
+  if (BJ_AHEAD_PRIO && ahead) __builtin_amdgcn_s_setprio(BJ_AHEAD_PRIO);
   int cur = 0;
   for (int st = 0; st < nst; ++st) {
     const int gen = st & 1;
@@ -538,92 +560,72 @@ __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 I
     real *Sw = S0 + (cur ^ 1) * BJ_W * BJ_ILD;
     const RotCS *cs = rot_cs + gen * BJ_B;
     int any; // does this step rotate anything?  Uniform (set before the barrier that ended the previous step).  The look-ahead wave asks
-             // for it BEHIND its operand reads: those are the step's first LDS requests, ahead of the workers' 192
-#if !BJ_AHEAD_ANY_LATE
-    any = rot_any[gen];
-#endif
-    if (worker) {
-#if BJ_AHEAD_ANY_LATE
+             // for it BEHIND its operand reads: those are the step's first LDS requests
+    if (!ahead) {
       any = rot_any[gen];
-#endif
-#if BJ_WORKER_SLEEP
-      __builtin_amdgcn_s_sleep(BJ_WORKER_SLEEP);
-#endif
       if (any) { // a step in which no pair is above the threshold changes nothing
-        int i11[BJ_NBLK], i12[BJ_NBLK], i21[BJ_NBLK], i22[BJ_NBLK], ip[BJ_NROW], iq[BJ_NROW];
-        RotCS r1[BJ_NBLK], r2[BJ_NBLK], rq[BJ_NROW];
-        real a11[BJ_NBLK], a12[BJ_NBLK], a21[BJ_NBLK], a22[BJ_NBLK], vp[BJ_NROW], vq[BJ_NROW];
-        bool same[BJ_NBLK];
+        if (sworker) { // every read of the lane in one batch, then the arithmetic, then the stores
+          const int qP = BJ_B + ((sP + st) & (BJ_B - 1)), qQ = BJ_B + ((sQ + st) & (BJ_B - 1));
+          const int lo = qP < qQ ? qP : qQ, hi = qP < qQ ? qQ : qP;
+          const int o11 = sP * BJ_ILD + sQ, o12 = sP * BJ_ILD + qQ, o21 = sQ * BJ_ILD + qP, o22 = lo * BJ_ILD + hi; // (diagonal block: o21 == o12)
+          const RotCS r1 = cs[sP], r2 = cs[sQ];
+          const real a11 = Sr[o11], a12 = Sr[o12], a21 = Sr[o21], a22 = Sr[o22];
+          real vq[4];
+          RotCS rq[4];
+          int oq[4];
+          if (qworker) {
 #pragma unroll
-        for (int u = 0; u < BJ_NBLK; ++u) {
-          const int e = tid + u * BJ_INNER_THREADS, Qi = e / NP, P = e % NP;
-          const int q1 = BJ_B + ((P + st) & (BJ_B - 1)), q2 = BJ_B + ((Qi + st) & (BJ_B - 1));
-          i11[u] = P * BJ_ILD + Qi;
-          i12[u] = P * BJ_ILD + q2;
-          i21[u] = q1 * BJ_ILD + Qi;
-          i22[u] = q1 * BJ_ILD + q2;
-          same[u] = P == Qi;
-          r1[u] = cs[P];
-          r2[u] = cs[Qi];
-          a11[u] = Sr[i11[u]];
-          a12[u] = Sr[i12[u]];
-          a21[u] = Sr[i21[u]];
-          a22[u] = Sr[i22[u]];
-        }
+            for (int j = 0; j < 4; ++j) {
+              const int Qi = qpair0 + 8 * j;
+              oq[j] = qrow * BJ_ILD + BJ_B + ((Qi + st) & (BJ_B - 1));
+              rq[j] = cs[Qi];
+              vq[j] = Q[oq[j]];
+            }
+          }
+          const Blk2 o = bj_block(a11, a12, a21, a22, r1, r2, diag && r1.s != (real)0);
+          Sw[o11] = o.n11;
+          Sw[o12] = o.n12;
+          Sw[o21] = diag ? o.n12 : o.n21; // (diagonal block: the same address as o12)
+          Sw[o22] = o.n22;
+          if (qworker) {
 #pragma unroll
-        for (int j = 0; j < BJ_NROW; ++j) {
-          const int f = tid + j * BJ_INNER_THREADS, Qi = f / BJ_W, i = f % BJ_W;
-          ip[j] = i * BJ_ILD + Qi;
-          iq[j] = i * BJ_ILD + BJ_B + ((Qi + st) & (BJ_B - 1));
-          rq[j] = cs[Qi];
-          vp[j] = Q[ip[j]];
-          vq[j] = Q[iq[j]];
-        }
-#pragma unroll
-        for (int u = 0; u < BJ_NBLK; ++u) {
-          const Blk2 o = bj_block(a11[u], a12[u], a21[u], a22[u], r1[u], r2[u], same[u] && r1[u].s != (real)0);
-          Sw[i11[u]] = o.n11;
-          Sw[i12[u]] = o.n12;
-          Sw[i21[u]] = o.n21;
-          Sw[i22[u]] = o.n22;
-        }
-#pragma unroll
-        for (int j = 0; j < BJ_NROW; ++j) {
-          Q[ip[j]] = fma(rq[j].c, vp[j], -(rq[j].s * vq[j]));
-          Q[iq[j]] = fma(rq[j].s, vp[j], rq[j].c * vq[j]);
+            for (int j = 0; j < 4; ++j) {
+              const real vp = qI[j];
+              qI[j] = fma(rq[j].c, vp, -(rq[j].s * vq[j]));
+              Q[oq[j]] = fma(rq[j].s, vp, rq[j].c * vq[j]);
+            }
+          }
         }
         if (tid == 0) rotated = 1;
       }
-    } else if (ahead && st + 1 < nst) {
-      // next step's pair: p' = ai, q' = 32 + (ai + st + 1) mod 32.  In THIS step p' is the first index of pair ai (partner qa), q' the
-      // second index of pair aj = (ai + 1) mod 32 (whose first index is aj).  The twelve offsets were formed before the barrier: the
-      // reads below are this wave's first instructions of the step and enter the LDS queue ahead of the workers' 192 (behind them they
-      // came back after 1340 clocks)
-      const real d11 = Sr[ao[0]], d12 = Sr[ao[1]], d21 = Sr[ao[2]], d22 = Sr[ao[3]];     // block (ai, ai): its n11 is S'[p'][p']
-      const real e11 = Sr[ao[4]], e12 = Sr[ao[5]], e21 = Sr[ao[6]], e22 = Sr[ao[7]];     // block (aj, aj): its n22 is S'[q'][q']
-      const real f11 = Sr[ao[8]], f12 = Sr[ao[9]], f21 = Sr[ao[10]], f22 = Sr[ao[11]];   // block (ai, aj): its n12 is S'[p'][q']
+    } else if (st + 1 < nst) {
+      // the ten offsets were formed before the barrier: these reads are the wave's first instructions of the step
+      const real d11 = Sr[ao[0]], d12 = Sr[ao[1]], d22 = Sr[ao[2]];
+      const real e11 = Sr[ao[3]], e12 = Sr[ao[4]], e22 = Sr[ao[5]];
+      const real f11 = Sr[ao[6]], f12 = Sr[ao[7]], f21 = Sr[ao[8]], f22 = Sr[ao[9]];
       const RotCS ri = cs[ai], rj = cs[aj];
 #if BJ_AHEAD_ANY_LATE
       any = rot_any[gen];
 #endif
 #if BJ_AHEAD_ONE_BATCH
-      __builtin_amdgcn_sched_barrier(0); // all fourteen reads in ONE round trip (the scheduler had split them into three, each queueing
-                                         // behind the workers' traffic: 1340 clocks before the last operand arrived)
+      __builtin_amdgcn_sched_barrier(0); // all reads in ONE round trip (left to itself the scheduler split them into three)
 #endif
       const int qn = BJ_B + ((ai + st + 1) & (BJ_B - 1));
-      const Blk2 bd = bj_block(d11, d12, d21, d22, ri, ri, ri.s != (real)0);
-      const Blk2 be = bj_block(e11, e12, e21, e22, rj, rj, rj.s != (real)0);
-      const Blk2 bf = bj_block(f11, f12, f21, f22, ri, rj, false);
-      BJ_FORM(gen ^ 1, qn, bd.n11, be.n22, bf.n12);
+      const Blk2 bd = bj_block(d11, d12, d12, d22, ri, ri, ri.s != (real)0);
+      const Blk2 be = bj_block(e11, e12, e12, e22, rj, rj, rj.s != (real)0);
+      const Blk2 bf = bj_block(f11, f12, f21, f22, ai < aj ? ri : rj, ai < aj ? rj : ri, false);
+      BJ_FORM(gen ^ 1, qn, bd.n11, be.n22, ai < aj ? bf.n12 : bf.n21);
       ahead_offsets(st + 1);
-    } else {
-#if BJ_AHEAD_ANY_LATE
+#if !BJ_AHEAD_ANY_LATE
       any = rot_any[gen];
 #endif
+    } else {
+      any = rot_any[gen];
     }
     __syncthreads();
     if (any) cur ^= 1;
   }
+#undef BJ_FORM
   offmax = block_max(offmax, red); // (contains the barriers that make `rotated` visible)
   if (tid == 0) {
     if (offmax > (real)0) atomicMax(&ctl->offmax_bits[offslot], bp_bits(offmax));
@@ -631,10 +633,17 @@ __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 I
   }
   if (!rotated) return; // uniform: nobody reads Q / S' of a pair whose flag is 0
   const real *Sf = S0 + cur * BJ_W * BJ_ILD;
-  for (int e = tid; e < BJ_W * BJ_W; e += nthr) {
-    const int r = e & (BJ_W - 1), c = e >> 6;
+  if (qworker) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Qg[(qpair0 + 8 * j) * BJ_W + qrow] = qI[j]; // I columns: from the registers
+  }
+  for (int e = tid; e < BJ_W * BJ_B; e += nthr) {                            // J columns: from LDS
+    const int r = e & (BJ_W - 1), c = BJ_B + (e >> 6);
     Qg[c * BJ_W + r] = Q[r * BJ_ILD + c];
-    Sg[c * BJ_W + r] = Sf[r * BJ_ILD + c];
+  }
+  for (int e = tid; e < BJ_W * BJ_W; e += nthr) { // S' from the triangle that was kept
+    const int r = e & (BJ_W - 1), c = e >> 6;
+    Sg[c * BJ_W + r] = r <= c ? Sf[r * BJ_ILD + c] : Sf[c * BJ_ILD + r];
   }
 }
 
