@@ -274,3 +274,29 @@ def test_lds_kernel_orders_73_to_92_warm_started_match_reference(cone):
         assert err <= 1e-11, (cone, rep, err)
     lib._scs_finish_cone(c)
     ref._scs_finish_cone(wr)
+
+
+@pytest.mark.parametrize("cone", [dict(s=[100, 131, 300]), dict(s=[257], cs=[70])])
+def test_fused_step_equals_the_two_launch_form(cone, monkeypatch):
+    """Round 4: one launch per outer step of the blocked Jacobi iteration (k_bj_fused: the inner sweep of step k + 1 beside the
+    update of step k, forming its subproblem from pre-update data with the update's own tile products).  The subproblem must have
+    the bits the update writes, so the whole projection must equal the two-launch form's (SCS_AMD_PSD_FUSED=0, read at init) to
+    rounding -- over a cold call and two warm-started ones, for blocks with different numbers of block columns in one launch."""
+    lib = _lib()
+    m = capi.cone_rows(cone)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SCS_AMD_PSD_FUSED", fused)
+        k = capi.make_cone(cone)
+        c = lib._scs_init_cone(C.byref(k), m)
+        assert c
+        res = []
+        x0 = np.random.default_rng(11).standard_normal(m)
+        for rep in range(3):
+            x = x0 + 0.05 * rep * np.random.default_rng(12 + rep).standard_normal(m)
+            assert lib._scs_proj_dual_cone(x.ctypes.data_as(T.fp), c, None, None) == 0
+            res.append(x)
+        outs[fused] = res
+        lib._scs_finish_cone(c)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), np.abs(a - b).max()

@@ -146,3 +146,83 @@ def test_emulated_blocked_iteration_converges_to_the_eigen_decomposition(k, cros
     assert np.abs(Vk.T @ Vk - np.eye(k)).max() <= 1e-12
     if V.shape[0] > k:  # padding rows / columns were never rotated
         assert np.abs(V[k:, :k]).max() == 0.0 and np.abs(V[:k, k:]).max() == 0.0
+
+
+def _fused_subproblem(old, pairs_k, res_k, g_next):
+    """The 64 x 64 subproblem of the NEXT step's pair (I', J') as k_bj_fused's inner workgroups form it from what the update of step k
+    reads -- the matrix before the step (`old`), and Q / S' / flag of step k's pairs (`res_k`): quadrants [I', I'] and [J', J'] are pieces
+    of the diagonal tiles of step k (S' of the pair that held the block column, or A itself if that pair did not rotate), [I', J'] is a
+    32 x 32 piece of Q_Pa' A[Pa, Pb] Q_Pb with the update's orientation Pa <= Pb (transposed when I' sat in the larger pair)."""
+    I, J = int(g_next[0]) // B, int(g_next[B]) // B
+
+    def where(X):
+        for pi, g in enumerate(pairs_k):
+            if g[0] // B == X:
+                return pi, 0
+            if g[B] // B == X:
+                return pi, 1
+        raise AssertionError("block column not in any pair")
+
+    def diag_tile(P):
+        Qm, Sp, rot, _ = res_k[P]
+        return Sp if rot else old[np.ix_(pairs_k[P], pairs_k[P])]
+
+    (PI, hI), (PJ, hJ) = where(I), where(J)
+    S = np.zeros((W, W))
+    sl = lambda h: slice(h * B, (h + 1) * B)
+    S[:B, :B] = diag_tile(PI)[sl(hI), sl(hI)]
+    S[B:, B:] = diag_tile(PJ)[sl(hJ), sl(hJ)]
+    if PI == PJ:
+        X = diag_tile(PI)[sl(hI), sl(hJ)]
+    else:
+        swap = PI > PJ
+        Pa, Pb, ha, hb = (PJ, PI, hJ, hI) if swap else (PI, PJ, hI, hJ)
+        Qa = res_k[Pa][0] if res_k[Pa][2] else np.eye(W)
+        Qb = res_k[Pb][0] if res_k[Pb][2] else np.eye(W)
+        O = Qa[:, sl(ha)].T @ (old[np.ix_(pairs_k[Pa], pairs_k[Pb])] @ Qb[:, sl(hb)])
+        X = O.T if swap else O
+    S[:B, B:] = X
+    S[B:, :B] = X.T
+    return S
+
+
+@pytest.mark.parametrize("k,cross", [(200, True), (131, False)])
+def test_fused_step_forms_the_subproblem_the_update_writes(k, cross):
+    """The index bookkeeping of k_bj_fused (psd_big.h): for every outer step of two sweeps, the subproblem assembled from pre-update
+    data equals the diagonal block of the updated matrix for the next step's pairing."""
+    rng = np.random.default_rng(k)
+    M = rng.standard_normal((k, k))
+    Ain = (M + M.T) / 2
+    K64 = (k + W - 1) // W * W
+    nbc, npairs = K64 // B, K64 // W
+    A = [np.zeros((K64, K64)), np.zeros((K64, K64))]
+    A[0][:k, :k] = Ain
+    cur, thr = 0, 1e-15 * np.linalg.norm(Ain) / k
+    osteps = nbc if cross else nbc - 1
+    checked = 0
+    for sweep in range(2):
+        for ostep in range(osteps):
+            kind = 0 if not cross else (1 if ostep == 0 else 2)
+            old, new = A[cur], A[cur ^ 1]
+            pairs = [gidx(bj_pair_sched(pi, ostep, nbc, cross)) for pi in range(npairs)]
+            res = [_inner(old[np.ix_(g, g)], g, k, thr, kind) for g in pairs]
+            for P in range(npairs):
+                for Qp in range(npairs):
+                    gp, gq, fP, fQ = pairs[P], pairs[Qp], res[P][2], res[Qp][2]
+                    if P == Qp and fP:
+                        new[np.ix_(gp, gq)] = res[P][1]
+                    elif not fP and not fQ:
+                        new[np.ix_(gp, gq)] = old[np.ix_(gp, gq)]
+                    else:
+                        QP = res[P][0] if fP else np.eye(W)
+                        QQ = res[Qp][0] if fQ else np.eye(W)
+                        new[np.ix_(gp, gq)] = QP.T @ (old[np.ix_(gp, gq)] @ QQ)
+            nstep = (ostep + 1) % osteps  # the last launch of a sweep runs the first inner sweep of the next one
+            for pi in range(npairs):
+                g_next = gidx(bj_pair_sched(pi, nstep, nbc, cross))
+                got = _fused_subproblem(old, pairs, res, g_next)
+                want = new[np.ix_(g_next, g_next)]
+                assert np.abs(got - want).max() <= 1e-13 * max(1.0, np.abs(want).max()), (sweep, ostep, pi)
+                checked += 1
+            cur ^= 1
+    assert checked == 2 * osteps * npairs
