@@ -580,6 +580,24 @@ def secondary_single_gpu(args, headline_prob=None):
         out["configs2_sdp"] = d
     except Exception as e:
         out["configs2_sdp"] = dict(error=str(e))
+    # ---- PSD blocks beyond the LDS path (orders > 92: blocked Jacobi iteration, one fused launch per outer step; VERDICT r3 item 2 set
+    # targets for exactly these three cases): ms per projection of all blocks, as scripts/bench_psd_sizes.py measures it
+    try:
+        lib = capi.load("libscsamd.so")
+        rows = []
+        for k, B in ((92, 64), (256, 8), (1024, 1)):
+            pr = problems.random_sdp(200, B, k, 2, 4, seed=1)
+            prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+            r = capi.solve(lib, prob, verbose=0, acceleration_lookback=0, max_iters=40, eps_abs=1e-12, eps_rel=1e-12, want_stats=True, profiling=True)
+            st = r["stats"]
+            rows.append(dict(order=k, blocks=B, ms_per_projection=st["cone_ms"] / max(st["cone_projs"], 1), projections_timed=st["cone_projs"],
+                             psd_unconverged=st.get("psd_unconverged")))
+        out["psd_large_blocks"] = dict(
+            workload="random SDPs with B PSD blocks of order k (92x64 = the largest order of the LDS kernel; 256x8 and 1024x1 = the blocked "
+                     "iteration of scs_amd/csrc/psd_big.h), 40 ADMM iterations each, cold start, HIP events around the cone kernels",
+            cases=rows, targets_ms="VERDICT r3: 92x64 <= 2, 256x8 <= 2.5, 1024x1 <= 10", evidence="profiles/r4_psd_fused_step.md")
+    except Exception as e:
+        out["psd_large_blocks"] = dict(error=str(e))
     # ---- the headline problem under the reference's DEFAULT settings: acceleration_lookback = 10 (include/glbopts.h:45),
     # Anderson acceleration device resident (scs_amd/csrc/aa_dev.hip; call sites src/scs.c:1359-1366, :1439-1447)
     try:

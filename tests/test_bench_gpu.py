@@ -80,6 +80,10 @@ def test_side_workloads_of_the_default_line_at_reduced_sizes():
     assert d["status"] == "solved" and d["roofline"]["bound"] == "hbm" and "parity_mode" in d
     s = d["secondary"]
     assert s["configs2_sdp"]["status"] == "solved" and s["configs2_sdp"]["ms_per_projection"] > 0
+    big = {(c["order"], c["blocks"]): c for c in s["psd_large_blocks"]["cases"]}  # PSD blocks beyond the LDS path (fused step)
+    assert set(big) == {(92, 64), (256, 8), (1024, 1)}
+    assert all(c["ms_per_projection"] > 0 and c["projections_timed"] > 0 and not c["psd_unconverged"] for c in big.values())
+    assert big[(92, 64)]["ms_per_projection"] < 3.0 and big[(256, 8)]["ms_per_projection"] < 4.0 and big[(1024, 1)]["ms_per_projection"] < 16.0
     f32 = s["configs4_fp32"]
     assert f32["status"] == "solved" and f32["iters_to_eps"] > 0
     rec = f32["final_fp64_host_recomputed"]  # the fp32 solver's own stopping test, re-done in fp64: within rounding of its limits
