@@ -300,3 +300,33 @@ def test_fused_step_equals_the_two_launch_form(cone, monkeypatch):
         lib._scs_finish_cone(c)
     for a, b in zip(outs["1"], outs["0"]):
         assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("env", [dict(SCS_AMD_PSD_CROSS="0"), dict(SCS_AMD_PSD_CROSS="0", SCS_AMD_PSD_FUSED="0"), dict(SCS_AMD_PSD_BLOCKED="0")])
+def test_measurement_forms_of_the_large_block_iteration_still_project(env, monkeypatch):
+    """The forms kept for A/B measurements -- full 63-step subproblem sweeps (SCS_AMD_PSD_CROSS=0; through the fused step and as two
+    launches) and round 2's single-column steps (SCS_AMD_PSD_BLOCKED=0) -- share the control record, the generic inner sweep and the
+    update with the shipped form: they must still agree with it (different rotation orders: to 1e-10 of scale, not to rounding)."""
+    lib = _lib()
+    cone = dict(s=[100, 150])
+    m = capi.cone_rows(cone)
+    x0 = np.random.default_rng(21).standard_normal(m)
+
+    def run():
+        k = capi.make_cone(cone)
+        c = lib._scs_init_cone(C.byref(k), m)
+        assert c
+        res = []
+        for rep in range(2):
+            x = x0 * (1.0 + 0.1 * rep)
+            assert lib._scs_proj_dual_cone(x.ctypes.data_as(T.fp), c, None, None) == 0
+            res.append(x)
+        lib._scs_finish_cone(c)
+        return res
+
+    want = run()
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    got = run()
+    for a, b in zip(got, want):
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), (env, np.abs(a - b).max())
