@@ -5,6 +5,10 @@
 //
 // Per big block (all in HBM, column-major, common leading dimension ld = even-padded largest order):
 //   two copies of A (K2 x K2 working matrix), V (eigenvectors), the carried eigenbasis, a small control record.
+// What ships (rounds 3-4) is the BLOCKED iteration further down: a tournament over 32-wide block columns, one fused launch per outer
+// step (k_bj_fused: the 64 x 64 subproblems of step k + 1 rotated beside the matrix-core update of step k), the cross sweep software-
+// pipelined (bj_inner_sweep_cross).  The single-column form described next is round 2's, kept behind SCS_AMD_PSD_BLOCKED=0 as the
+// baseline of the measurements, and shares the control record, the sweep bookkeeping, the warm start and the reconstruction with it.
 // One Jacobi step = ONE launch over all big blocks (blockIdx.y = block), k_bp_step: A is double-buffered (the step reads
 // the matrix as it stood when the step began and writes the other copy), so every workgroup can form the rotations it
 // needs straight from A without racing the workgroups that are rewriting those entries -- no separate "parameters"
@@ -18,7 +22,7 @@
 // Reconstruction X+ = W W' (W = V diag(sqrt(max(lambda, 0)))) runs on the fp64 matrix cores over all CUs (k_bp_gram).
 // Everything is deterministic: no atomics in sums (the one atomic is a max), one workgroup owns every reduction.
 //
-// Measured (profiles/r2_bench_psd_sizes_*.jsonl): see DESIGN.md section 6.
+// Measured (profiles/r2_bench_psd_sizes_*.jsonl, r3_*, r4_psd_fused_step.md): see DESIGN.md section 6.
 #pragma once
 
 namespace scsamd {
