@@ -226,3 +226,38 @@ def test_fused_step_forms_the_subproblem_the_update_writes(k, cross):
                 checked += 1
             cur ^= 1
     assert checked == 2 * osteps * npairs
+
+
+def test_cross_sweep_items_cover_the_upper_triangle_once_per_step_and_the_look_ahead_reads_the_right_blocks():
+    """The lane bookkeeping of bj_inner_sweep_cross (psd_big.h), restated: in every step the 496 off-diagonal blocks (P < Q) and the 32
+    diagonal blocks write every entry of the UPPER triangle (r <= c in local order) exactly once -- rows {P, q(P)} x columns {Q, q(Q)},
+    q(i) = 32 + (i + st) mod 32, with S[q(P)][Q] kept at its mirror (Q, q(P)) and S[q(P)][q(Q)] at (min, max) -- and the ten entries a
+    look-ahead lane reads are the operands of the three blocks whose n11 / n22 / n12-or-n21 are S'[p'][p'], S'[q'][q'], S'[p'][q'] of
+    ITS next pair (p' = i, q' = 32 + (i + st + 1) mod 32)."""
+    q = lambda i, st: B + ((i + st) % B)
+    for st in range(B):
+        seen = np.zeros((W, W), dtype=int)
+        for Q in range(B):
+            for P in range(Q + 1):
+                qP, qQ = q(P, st), q(Q, st)
+                lo, hi = min(qP, qQ), max(qP, qQ)
+                offs = [(P, Q), (P, qQ), (Q, qP), (lo, hi)] if P < Q else [(P, P), (P, qP), (qP, qP)]
+                for r, c in offs:
+                    assert r <= c
+                    seen[r, c] += 1
+        assert (seen[np.triu_indices(W)] == 1).all() and seen[np.tril_indices(W, -1)].sum() == 0
+        # the full-matrix meaning of a block's four operands: a11 = S[P][Q], a12 = S[P][qQ], a21 = S[qP][Q], a22 = S[qP][qQ]
+        for i in range(B):
+            j = (i + 1) % B
+            qa, qn = q(i, st), q(i, st + 1)
+            assert qn == q(j, st)  # next step's partner of i is this step's partner of pair i + 1
+            fP, fQ = min(i, j), max(i, j)
+            qPf, qQf = (qa, qn) if i < j else (qn, qa)
+            ao = [(i, i), (i, qa), (qa, qa), (j, j), (j, qn), (qn, qn), (fP, fQ), (fP, qQf), (fQ, qPf), (min(qPf, qQf), max(qPf, qQf))]
+            assert all(r <= c for r, c in ao)
+            # block (i, i): rows {i, qa} x cols {i, qa}: n11 is entry (i, i) = (p', p')
+            # block (j, j): rows {j, qn} x cols {j, qn}: n22 is entry (qn, qn) = (q', q')
+            # block (fP, fQ): rows {fP, q(fP)} x cols {fQ, q(fQ)}: n12 = (fP, q(fQ)), n21 = (q(fP), fQ)
+            want = (i, qn)  # (p', q')
+            got = (fP, qQf) if i < j else (fQ, qPf)  # n12's row/col if i < j, else the mirror of n21 = (q(fP), fQ) -> (fQ, q(fP))
+            assert got == want, (st, i, got, want)
