@@ -599,14 +599,32 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     if (tid < 2) rot_any[tid] = 0;
     __syncthreads();
     for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+      // (round 4) a sweep that would rotate nothing is not run: one pass over the off-diagonal entries instead of K2 - 1 steps of pair
+      // scans.  The warm-started iteration of consecutive ADMM iterates ends with exactly such a verifying sweep; skipping it leaves the
+      // same A and V (a sweep without rotations changes nothing).
+      {
+        real m = 0;
+        for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+          const int i = e / K2, j = e % K2;
+          if (i < j && j < k) {
+            const real v = absval(A[MI(i, j)]);
+            m = v > m ? v : m;
+          }
+        }
+        m = block_max(m, red);
+        if (m <= thr) break;
+      }
       real offmax = 0;
+      // round-robin pairing: player 0 fixed, the others rotate -- pair i of step s is (0 or 1 + (i - 1 + s) mod (K2 - 1),
+      // 1 + (K2 - 2 - i + s) mod (K2 - 1)); the two positions advance by one per step (no run-time modulus on the step's critical path)
+      int pos_a = tid, pos_b = K2 - 1 - tid; // step 0 (for tid < npairs: i - 1 < K2 - 1 and K2 - 2 - i >= 0)
       for (int step = 0; step < K2 - 1; ++step) {
         const int par = step & 1;
-        // round-robin pairing: player 0 fixed, the others rotate
         if (tid < npairs) {
           const int i = tid;
-          int p = i == 0 ? 0 : 1 + ((i - 1 + step) % (K2 - 1));
-          int q = 1 + ((K2 - 2 - i + step) % (K2 - 1));
+          int p = pos_a, q = pos_b;
+          if (i != 0) pos_a = pos_a == K2 - 1 ? 1 : pos_a + 1;
+          pos_b = pos_b == K2 - 1 ? 1 : pos_b + 1;
           if (p > q) {
             const int t = p;
             p = q;
