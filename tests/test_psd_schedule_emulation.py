@@ -261,3 +261,22 @@ def test_cross_sweep_items_cover_the_upper_triangle_once_per_step_and_the_look_a
             want = (i, qn)  # (p', q')
             got = (fP, qQf) if i < j else (fQ, qPf)  # n12's row/col if i < j, else the mirror of n21 = (q(fP), fQ) -> (fQ, q(fP))
             assert got == want, (st, i, got, want)
+
+
+@pytest.mark.parametrize("K2", [2, 4, 6, 50, 64, 92])
+def test_incremental_round_robin_positions_equal_the_closed_form(K2):
+    """k_psd_jacobi (cones.hip) advances the two positions of a lane's pair by one per step (wrapping from K2 - 1 to 1, position 0
+    fixed) instead of evaluating pair i of step s = (0 or 1 + (i - 1 + s) mod (K2 - 1), 1 + (K2 - 2 - i + s) mod (K2 - 1)): the same
+    pairs, every index pair exactly once per sweep."""
+    met = set()
+    for i in range(K2 // 2):
+        a, b = i, K2 - 1 - i
+        for step in range(K2 - 1):
+            p = 0 if i == 0 else 1 + ((i - 1 + step) % (K2 - 1))
+            q = 1 + ((K2 - 2 - i + step) % (K2 - 1))
+            assert (a, b) == (p, q)
+            met.add((min(p, q), max(p, q)))
+            if i != 0:
+                a = 1 if a == K2 - 1 else a + 1
+            b = 1 if b == K2 - 1 else b + 1
+    assert len(met) == K2 * (K2 - 1) // 2
