@@ -832,6 +832,7 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_update(BigPsdView B, cons
 // Q / S' / flags are double-buffered by launch (the update of step k reads step k's while the inner sweep writes step k + 1's).
 // The last launch of a sweep runs the FIRST inner sweep of the next sweep before k_bp_sweep_end has closed this one (its
 // off-diagonal maximum goes to the other parity slot of the control record); if the block turns out converged the work is dropped.
+static_assert(BJ_UPD_THREADS == BJ_UPD_THREADS_MAX && BJ_INNER_LAUNCH == BJ_UPD_THREADS_MAX, "bj_inner_sweep_cross lays its roles out over a 1024-thread workgroup");
 struct BjFusedArgs {
   int slot;        // launch parity of the control record's `cur` (as `arg & 1` of the two-launch form)
   int do_update;   // 0: the first launch of a projection (inner sweep of step 0 only)
