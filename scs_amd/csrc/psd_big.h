@@ -479,11 +479,12 @@ __device__ __forceinline__ Blk2 bj_block(real a11, real a12, real a21, real a22,
 //    replaced and apply the current step's rotations to just the three entries their next pair needs (S[p'][p'], S[q'][q'], S[p'][q']:
 //    three 2x2 blocks, the same bj_block as the update, hence the same bits).  One barrier per step.  Round 3 measured this form slower
 //    (114 vs 96 us per sweep): the look-ahead chain then went through pair tables and an fp64 sqrt / div / rsqrt sequence.
-//  * the update is bound by LDS throughput (192 wave reads in 690 clocks = the 128 B / clock of the LDS, the same again for the stores),
-//    so it moves less: only the UPPER triangle of the symmetric S is kept (r <= c in local order; 496 off-diagonal 2x2 blocks P < Q and
-//    32 diagonal ones instead of 1024 blocks), and the I column of every (row, pair) item of Q never leaves its lane's registers (a
-//    lane keeps its items for the whole sweep; only the J columns, which change partner every step, live in LDS).  5280 + 6144 LDS
-//    accesses per step instead of 20480, two thirds of the arithmetic.
+//  * the update moves and computes less: only the UPPER triangle of the symmetric S is kept (r <= c in local order; 496 off-diagonal
+//    2x2 blocks P < Q and 32 diagonal ones instead of 1024 blocks), and the I column of every (row, pair) item of Q never leaves its
+//    lane's registers (a lane keeps its items for the whole sweep; only the J columns, which change partner every step, live in LDS):
+//    5280 + 6144 LDS accesses per step instead of 20480, two thirds of the arithmetic.  (It bought 1 %: a step turned out to be a
+//    chain of latencies -- barrier, the flag's and the operands' LDS round trips, ~130 instructions per worker wave, the stores'
+//    completion: 0.98 us -- not a throughput problem.  Kept because it is the leaner form.)
 //  * waves 0-7 carry the update (a block of S and four items of Q per lane; the arithmetic is a quarter of a wave's instructions, so
 //    fewer waves with more items each beat fifteen waves with one or two), wave 15 looks ahead, the others only keep the barriers company.
 __device__ __forceinline__ void bj_inner_sweep_cross(unsigned char *smem, int2 IJ, int k, real thr, BigPsdCtl *ctl, int offslot, real *Qg, real *Sg,
