@@ -16,6 +16,21 @@ PARITY_WINDOW_MAX = 0.8  # measured 0.399 (gpurun_out r4a: n=6e4, 2-iteration wi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line_and_detail(out):
+    """stdout = ONE compact JSON line (what the driver parses, < 4 KB); the full record it summarises is in `detail_file`.
+    Returns the full record after checking the line against it."""
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0], out.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    c = json.loads(lines[0])
+    d = json.load(open(c["detail_file"]))
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "dtype", "data", "scaling", "higher_is_better", "status"):
+        assert c[k] == d[k], k
+    assert abs(c["value"] - d["value"]) <= 1e-5 * abs(d["value"]) and abs(c["ms_per_step"] - d["ms_per_step"]) <= 1e-5 * d["ms_per_step"]
+    assert c["config"]["n"] == d["config"]["n"] and "roofline" in c and "cpu_baseline" in c
+    return d
+
+
 def test_two_ranks_share_one_gpu_and_report_one_line():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--n", "20000",
@@ -23,9 +38,7 @@ def test_two_ranks_share_one_gpu_and_report_one_line():
                           "--batch-per-gpu", "2", "--batch-concurrency", "2"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = _line_and_detail(out)
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == [0, 1]
     assert d["status"] == "solved" and d["value"] > 0 and d["steps"] == 10
     assert len(d["results_per_rank"]) == 2 and all(r[1] > 0 for r in d["results_per_rank"])
@@ -41,9 +54,7 @@ def _run_bench(extra, timeout=900):
                           "--secondary", "batch", "--batch-n", "20000", "--batch-per-gpu", "2", "--batch-concurrency", "2"] + extra,
                          env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    return _line_and_detail(out)
 
 
 def test_one_rank_under_torchrun_runs_its_collectives_over_rccl():
@@ -74,9 +85,7 @@ def test_side_workloads_of_the_default_line_at_reduced_sizes():
                           "--cpu-window-iters", "2", "--parity-threads", "4", "--aa-window-threads", "4"], env=env, capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _line_and_detail(out)
     assert d["status"] == "solved" and d["roofline"]["bound"] == "hbm" and "parity_mode" in d
     s = d["secondary"]
     assert s["configs2_sdp"]["status"] == "solved" and s["configs2_sdp"]["ms_per_projection"] > 0

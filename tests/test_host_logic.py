@@ -173,11 +173,53 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == [0, 1]
     assert d["steps"] == 3 and d["warmup"] == 1
-    assert len(d["results_per_rank"]) == 2
+    assert len(d["results_per_rank"]) == 2 and len(d["per_rank_it_per_s"]) == 2
     iters = [int(r[1]) for r in d["results_per_rank"]]
     assert iters == [50, 75]  # the stub's ranks converge at different iterations
     # value = all ranks' iterations / the slowest rank's wall time; the window figure is separate
     assert d["value"] > 0 and d["window_it_per_s"] > 0 and abs(d["ms_per_step"] - 2.0) < 2.0
+
+
+def test_bench_line_is_compact_and_carries_the_contract_keys(tmp_path):
+    """the driver could not parse a 21 KB line.  The LAST stdout line must be one compact JSON object
+    (< 4096 bytes) with the contract's keys; the full record goes to `detail_file` and, prefixed, to stderr.  Checked twice:
+    on the stub launch path end to end, and on round 4's full 21 KB record (the worst case the builder has produced)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SCS_BENCH_DETAIL"] = str(tmp_path / "detail.json")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--stub-solver", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_MAX_BYTES
+    d = json.loads(lines[0])
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline", "detail_file"}
+    assert need <= set(d), need - set(d)
+    assert {"workload", "n", "m", "nnz"} <= set(d["config"]) and {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"} <= set(d["roofline"])
+    assert json.loads(json.dumps(d)) == d
+    full = json.load(open(d["detail_file"]))
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and "results_per_rank" in full
+    det = [l for l in out.stderr.splitlines() if l.startswith(bench.DETAIL_PREFIX)]
+    assert len(det) == 1 and json.loads(det[0][len(bench.DETAIL_PREFIX):])["steps"] == 3
+    big = json.load(open(os.path.join(root, "profiles", "r4_bench_default_v6.json")))  # the line that broke the parser
+    c = bench.compact_line(big, "/x/detail.json")
+    s = json.dumps(c, separators=(",", ":"))
+    assert len(s) < bench.LINE_MAX_BYTES and need <= set(c)
+    assert {"value", "unit", "cores", "kind", "sample", "host_cores", "cpu_model"} <= set(c["cpu_baseline"]) and len(c["cpu_baseline"]["sample"]) <= 200
+    assert c["roofline"]["frac"] == pytest.approx(big["roofline"]["frac"], rel=1e-5)
+    assert c["parity_window"]["max_rel_diff"] == pytest.approx(big["parity_window"]["max_rel_diff"], rel=1e-5)
+    assert c["batch"]["parity"]["ok"] is True and c["secondary"]["configs2_sdp"]["ms_per_projection"] > 0
+    # an absurdly inflated record still yields a parseable line: optional blocks are shed, the contract keys stay
+    big["config"]["workload"] = "x" * 5000
+    big["secondary"]["locality_variant"] = {"k%d" % i: dict(roofline=dict(frac=0.1)) for i in range(400)}
+    c = bench.compact_line(big, "/x/detail.json")
+    assert len(json.dumps(c, separators=(",", ":"))) < bench.LINE_MAX_BYTES and need <= set(c)
 
 
 def test_row_slabs_of_the_sharded_linear_system_cover_every_row_once():
