@@ -1521,6 +1521,7 @@ void scs_amd_get_reorder_info(const ScsWork *w, double *out) {
 // numbering (identity when none is kept); info as scs_amd_get_reorder_info.  Returns 1 if a renumbering was kept, 0 if not, <0 on error.
 scs_int scs_amd_plan_reorder(const ScsMatrix *A, const ScsCone *k, scs_int *col_new2old, scs_int *row_new2old, double *info) {
   if (!A || !k || !col_new2old || !row_new2old) return -1;
+  if (k->z < 0 || k->l < 0 || (long long)k->z + k->l > (long long)A->m) return -1; // plan_reorder indexes rows [0, z + l)
   try {
     HostCsc a;
     a.copy_from(A);

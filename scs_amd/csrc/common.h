@@ -34,14 +34,11 @@ struct HipError : std::runtime_error {
 };
 // Fault injection (tests of the failure convention): every HIP runtime call of this library goes through
 // HIP_CHECK, so ONE countdown covers allocations, copies, synchronisations and the post-launch error polls.  Armed by
-// scs_amd_test_fail_at(k) or the environment (SCS_AMD_FAIL_AT=k, read once): the k-th checked call from then on is
-// reported as hipErrorOutOfMemory although it succeeded; the countdown then disarms itself.  Never armed in normal use
-// (one relaxed atomic load per checked call).
+// the explicit test entry point scs_amd_test_fail_at(k) ONLY (round 5, ADVICE r4: no environment variable arms it -- a stray
+// variable must not make a production HIP call report OOM): the k-th checked call from then on is reported as
+// hipErrorOutOfMemory although it succeeded; the countdown then disarms itself.  One relaxed atomic load per checked call.
 inline std::atomic<long long> &fail_countdown() {
-  static std::atomic<long long> c{[] {
-    const char *e = getenv("SCS_AMD_FAIL_AT");
-    return e ? atoll(e) : 0LL;
-  }()};
+  static std::atomic<long long> c{0LL};
   return c;
 }
 inline void hip_check(hipError_t e, const char *what, const char *file, int line) {

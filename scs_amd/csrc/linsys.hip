@@ -709,11 +709,17 @@ LinSys::~LinSys() {
 template <int E, int WPB, int MODE>
 static void launch_lockstep_one(const WaveRowsDev &wd, int g, size_t lds, hipStream_t stream, const WaveView &v, const real *x, real *y,
                                 const EpiArgs &e, const int *skip) {
-  static bool attr_set = false; // many waves' accumulators can pass the 64 KB a kernel gets without asking
-  if (!attr_set) {
+  // many waves' accumulators can pass the 64 KB a kernel gets without asking.  The opt-in is state of the function ON ONE DEVICE and the
+  // library serves several devices (and host threads) per process: one flag per device, set under a lock
+  static std::atomic<unsigned long long> attr_set[4] = {};
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  const bool tracked = dev >= 0 && dev < 256;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!tracked || !(attr_set[(dev >> 6) & 3].load(std::memory_order_acquire) & bit)) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csr_wave_lockstep_kernel<E, WPB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   144 * 1024));
-    attr_set = true;
+    if (tracked) attr_set[(dev >> 6) & 3].fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((csr_wave_lockstep_kernel<E, WPB, MODE>), dim3(g), dim3(WPB * 64), lds, stream, v, x, y, e, skip, wd.accrows);
 }
@@ -722,7 +728,7 @@ static void launch_lockstep(const WaveRowsDev &wd, int g, size_t lds, hipStream_
                             const EpiArgs &e, const int *skip) {
 #define LS_CASE(W, M)                                                                                                  \
   if (wd.ls_wpb == W && wd.ls_bmode == M) return launch_lockstep_one<E, W, M>(wd, g, lds, stream, v, x, y, e, skip);
-  LS_CASE(16, 4) LS_CASE(16, 1) LS_CASE(8, 4)
+  LS_CASE(16, 4) LS_CASE(16, 1) LS_CASE(8, 4) LS_CASE(8, 1)
 #undef LS_CASE
   throw HipError("scs_amd: lockstep SpMV variant not instantiated");
 }

@@ -16,7 +16,18 @@
 #include <condition_variable>
 #include <dlfcn.h>
 #include <mutex>
-#include <rccl/rccl.h>
+
+// The five RCCL entry points used here, declared locally: the product libraries must build on a ROCm install without the
+// RCCL development headers -- the library itself is only ever dlopen'ed.  Values are those of the NCCL C API
+// (nccl.h: ncclUniqueId is 128 opaque bytes; ncclSuccess = 0; ncclFloat = 7, ncclDouble = 8; ncclSum = 0, ncclMax = 2).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
+}
 
 namespace scsamd {
 
