@@ -10,9 +10,12 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
-# measured on the GPU box (profiles/r4_*): largest relative difference over all rows / columns of the two per-iteration logs at
-# the reduced test size, times two ("replace < 0.25 by the measured figure x 2")
-PARITY_WINDOW_MAX = 0.8  # measured 0.399 (gpurun_out r4a: n=6e4, 2-iteration window), x 2; at the headline size: 0.206 over 5 iterations
+PARITY_ROW2_MAX, PARITY_LAST_MAX = 0.1, 0.8  # provisional until measured at this size
+# Per-iteration bounds on the two per-iteration logs (same problem, same iterations, same logged tolerance schedule; worst column
+# of each row).  Row 0: the first linear solve runs to the 1e-12 floor on both sides -> rounding only.  Row 1: one inexact solve
+# apart (O(CG tolerance) of a residual that is still large).  From row 2 on two valid inexact trajectories separate (DESIGN.md
+# section 4); the last bounds are the figures measured on the GPU box at this test's size x 2.
+PARITY_WINDOW_BOUNDS = [1e-10, 1e-3, PARITY_ROW2_MAX, PARITY_LAST_MAX]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -121,8 +124,11 @@ def test_side_workloads_of_the_default_line_at_reduced_sizes():
         assert legs and legs[0]["cores"] == 4 and legs[0]["value"] > 0
         pw = d["parity_window"]  # same problem, same iterations, same (logged) schedule: every row of the two logs side by side
         assert pw["rows"] == 4 and len(pw["rel_diff_per_iter"]) == 4 and [r["iter"] for r in pw["gpu"]] == [0, 1, 2, 3]
-        assert pw["rel_diff_per_iter"][0]["res_pri"] < 1e-6  # iteration 0 solves to the 1e-12 floor on both sides
-        assert pw["max_rel_diff"] < PARITY_WINDOW_MAX, pw["rel_diff_per_iter"]
+        # per-iteration bounds: row j = the state after iteration j, worst column of the row
+        worst = [max(v for k, v in r.items() if k != "iter" and isinstance(v, float)) for r in pw["rel_diff_per_iter"]]
+        print("parity_window worst-per-row:", worst)
+        for j, (w, bound) in enumerate(zip(worst, PARITY_WINDOW_BOUNDS)):
+            assert w <= bound, (j, w, bound, pw["rel_diff_per_iter"])
         bp = d["batch"]["parity"]  # one configs[3]-shaped problem to TERMINATION on both sides
         assert bp["ok"] is True and bp["same_status"] and bp["ours_verify"]["ok"], bp
         assert 0.5 <= bp["iter_ratio"] <= 2.0 and bp["pobj_rel_diff"] <= 1e-3

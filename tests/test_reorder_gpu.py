@@ -101,3 +101,72 @@ def test_pure_lp_renumbered_through_the_graph_search_gives_the_same_answer(monke
         assert d <= 1e-8, (v, d)   # measured 1.2e-9: 120 ADMM iterations of 1e-12 solves in two summation orders
     for k in ("pobj", "dobj", "res_pri", "res_dual", "gap"):
         assert abs(on["info"][k] - off["info"][k]) <= 1e-7 * max(1.0, abs(off["info"][k])), k
+
+
+def _session(lib, prob, b2, c2, warm0, exact, **over):
+    """scs_init -> cold solve -> scs_update(b2, c2) -> warm solve from the previous solution -> (fresh workspace) solve warm-started from
+    `warm0`, all through the public API of `lib` (ours or the reference's); returns the three (x, y, s, info) records."""
+    T = lib._scs_types
+    st = capi.default_settings(lib, verbose=0, acceleration_lookback=0, **over)
+    out = []
+    w = lib.scs_init(C.byref(prob.data), C.byref(prob.k), C.byref(st))
+    assert w
+    if exact:
+        lib.scs_amd_set_cg_tol_override(w, 1e-12)
+    x, y, s = np.zeros(prob.n), np.zeros(prob.m), np.zeros(prob.m)
+    sol = T.ScsSolution(x.ctypes.data_as(T.fp), y.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp))
+    inf = T.ScsInfo()
+    lib.scs_solve(w, C.byref(sol), C.byref(inf), 0)
+    out.append(dict(x=x.copy(), y=y.copy(), s=s.copy(), info=capi.info_dict(inf)))
+    assert lib.scs_update(w, b2.ctypes.data_as(T.fp), c2.ctypes.data_as(T.fp)) == 0
+    lib.scs_solve(w, C.byref(sol), C.byref(inf), 1)  # warm: the caller's vectors go IN through the renumbering too
+    out.append(dict(x=x.copy(), y=y.copy(), s=s.copy(), info=capi.info_dict(inf)))
+    lib.scs_finish(w)
+    w = lib.scs_init(C.byref(prob.data), C.byref(prob.k), C.byref(st))
+    assert w
+    if exact:
+        lib.scs_amd_set_cg_tol_override(w, 1e-12)
+    x[:], y[:], s[:] = warm0
+    lib.scs_solve(w, C.byref(sol), C.byref(inf), 1)
+    out.append(dict(x=x.copy(), y=y.copy(), s=s.copy(), info=capi.info_dict(inf)))
+    lib.scs_finish(w)
+    return out
+
+
+def test_renumbered_solve_warm_start_and_update_match_the_reference_exact_cg(monkeypatch):
+    """the renumbering maps b, c, warm starts, scs_update vectors and (x, y, s) across the API
+    boundary; the tests above compare the library with itself.  Here the REFERENCE (oracle/_ref exactcg flavour: every linear
+    system to the 1e-12 floor, include/glbopts.h:253-255 hook) solves a scrambled banded SOCP with mixed zero / nonnegative /
+    second-order cones in the caller's numbering, and this library solves it with the renumbering ON: equal iteration counts and
+    1e-6 on every ScsInfo figure and on x, y, s in the CALLER's order -- for the cold solve, for the solve after scs_update(b, c),
+    and for a solve warm-started from a perturbed point (cone row order is an ABI fact, include/scs.h:121-172)."""
+    from oracle import pyoracle
+    if not pyoracle.ref_available("libscsindir_ref_exactcg.so"):
+        pytest.skip("oracle/_ref/libscsindir_ref_exactcg.so not built")
+    ref = pyoracle.load_ref("libscsindir_ref_exactcg.so")
+    lib = capi.load("libscsamd.so")
+    n, m = 40000, 80000
+    scr = problems.scramble_prob(problems.random_socp(n, m, 10, seed=23, band=BAND), 5)
+    assert scr["cone"]["z"] > 0 and scr["cone"]["l"] > 0 and len(scr["cone"]["q"]) > 2
+    prob = capi.Problem(scr["A"], scr["b"], scr["c"], scr["cone"])
+    rng = np.random.default_rng(5)
+    b2 = (prob.b * 1.05).copy()  # uniform: stays feasible
+    c2 = (prob.c * 0.9).copy()
+    warm0 = (0.1 * rng.standard_normal(prob.n), 0.1 * rng.standard_normal(prob.m), 0.1 * rng.standard_normal(prob.m))
+    over = dict(eps_abs=1e-2, eps_rel=1e-2, max_iters=400)  # exact CG on one host core: ~0.3 s per ADMM iteration at this size
+    want = _session(ref, prob, b2, c2, warm0, exact=False, **over)
+    monkeypatch.setenv("SCS_AMD_REORDER", "1")  # forced: 4e5 nonzeros is below the library's own threshold
+    info = _reorder_info(lib, prob)
+    assert info[0] == 1.0 and 0.5 * (info[3] + info[4]) < 0.25 * (info[1] + info[2]), info
+    got = _session(lib, prob, b2, c2, warm0, exact=True, **over)
+    for stage, (g, r) in enumerate(zip(got, want)):
+        gi, ri = g["info"], r["info"]
+        assert gi["status_val"] == ri["status_val"] == 1, (stage, gi["status"], ri["status"])
+        assert gi["iter"] == ri["iter"], (stage, gi["iter"], ri["iter"])
+        assert gi["scale_updates"] == ri["scale_updates"], stage
+        for k in ("pobj", "dobj", "res_pri", "res_dual", "gap", "scale"):
+            assert abs(gi[k] - ri[k]) <= 1e-6 * max(abs(gi[k]), abs(ri[k]), 1e-3), (stage, k, gi[k], ri[k])
+        for v in ("x", "y", "s"):
+            d = np.abs(g[v] - r[v]).max() / max(1.0, np.abs(r[v]).max())
+            assert d <= 1e-6, (stage, v, d)
+    assert want[1]["info"]["iter"] < want[0]["info"]["iter"]  # the warm solve after the update really started from the old point
