@@ -10,12 +10,13 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
-PARITY_ROW2_MAX, PARITY_LAST_MAX = 0.1, 0.8  # provisional until measured at this size
 # Per-iteration bounds on the two per-iteration logs (same problem, same iterations, same logged tolerance schedule; worst column
-# of each row).  Row 0: the first linear solve runs to the 1e-12 floor on both sides -> rounding only.  Row 1: one inexact solve
-# apart (O(CG tolerance) of a residual that is still large).  From row 2 on two valid inexact trajectories separate (DESIGN.md
-# section 4); the last bounds are the figures measured on the GPU box at this test's size x 2.
-PARITY_WINDOW_BOUNDS = [1e-10, 1e-3, PARITY_ROW2_MAX, PARITY_LAST_MAX]
+# of each row).  Row 0: the first linear solve runs to the 1e-12 floor on both sides -> rounding only.  Row 1: one
+# inexact solve apart (O(CG tolerance) of a residual that is still large).  From row 2 on two valid inexact trajectories separate
+# (DESIGN.md section 4).  Measured on the GPU box at this test's size (n = 1.2e5, gpurun_out/r5a): 9.0e-13, 9.0e-4, 0.146, 0.146
+# (the last row repeats the returned state) -- the bounds are those figures x 2 (row 0: the 1e-10 asked for).  At the headline size
+# the same rows measure 3.6e-14, 6.7e-5, 6.8e-3, 0.215 (bench line, parity_window.max_rel_diff_by_iter).
+PARITY_WINDOW_BOUNDS = [1e-10, 1.8e-3, 0.3, 0.3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
