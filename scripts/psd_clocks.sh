@@ -1,0 +1,35 @@
+#!/bin/bash
+# phase clocks of k_psd_jacobi on configs[2] (200 blocks of 50 x 50, warm started): the instrumented variant
+# (scripts/build_variant.sh psdclk -DSCSAMD_PSD_CLOCKS, built beforehand -- it travels with the snapshot) swapped in for the run,
+# pipelined step (SCS_AMD_PSD_PIPE=1, shipped) and two-phase step (=0) back to back.  Output: gpurun_out/<tag>/psd_clocks.md
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/${1:-psdclk}
+mkdir -p $OUT
+cd $R
+cp scs_amd/lib/libscsamd.so /tmp/lib_shipped.so
+cp scs_amd/lib_var/psdclk/libscsamd.so scs_amd/lib/libscsamd.so
+: > $OUT/psd_clocks.md
+for pipe in 1 0; do
+  SCS_AMD_PSD_PIPE=$pipe timeout 300 python scripts/bench_sdp.py ${2:-} > $OUT/psdclk_pipe$pipe.log 2>&1
+  python - $OUT/psdclk_pipe$pipe.log $pipe >> $OUT/psd_clocks.md <<'PY'
+import sys, re
+rows = []
+for l in open(sys.argv[1]):
+    if l.startswith("PSDCLK"):
+        f = l.split()
+        rows.append({f[i]: float(f[i + 1]) for i in range(1, len(f) - 1, 2)})
+cone = [l.strip() for l in open(sys.argv[1]) if l.startswith("cone:")]
+if not rows:
+    print("pipe", sys.argv[2], ": no PSDCLK lines"); sys.exit(0)
+n = len(rows)
+avg = {k: sum(r[k] for r in rows) / n for k in rows[0]}
+tot = avg["unpack_warm"] + avg["fro"] + avg["sweeps"] + avg["tail"]
+print(f"| SCS_AMD_PSD_PIPE={sys.argv[2]} ({'pipelined step' if sys.argv[2]=='1' else 'two-phase step'}) | launches {n} | clocks per launch {tot:.0f} "
+      f"| unpack+warm {avg['unpack_warm']:.0f} | fro {avg['fro']:.0f} | sweeps {avg['sweeps']:.0f} ({100*avg['sweeps']/tot:.0f} %) | W, WW', pack {avg['tail']:.0f} "
+      f"| sweeps per launch {avg['nsweep']:.2f} | steps {avg['steps']:.1f} | rotating steps {avg['rot_steps']:.1f} "
+      f"| clocks per rotating step {avg['sweeps']/max(avg['rot_steps'],1):.0f} | {cone[0] if cone else ''} |")
+PY
+done
+cp /tmp/lib_shipped.so scs_amd/lib/libscsamd.so
+cat $OUT/psd_clocks.md

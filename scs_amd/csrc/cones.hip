@@ -25,6 +25,7 @@
 #include "cones.h"
 #include "cones_exp_pow.h"
 #include <algorithm>
+#include "psd_lds_step.h" // RotCS, jacobi_cs, psd_update_pass, the look-ahead of the pipelined step
 
 namespace scsamd {
 
@@ -39,6 +40,17 @@ constexpr int PSD_MAX_SWEEPS = 30;
 constexpr int PSD_WARM_KMAX = 72;     // warm start keeps a third K2 x ld matrix in LDS: 3*72*73*8 B + header < 160 KB
 constexpr int PSD_WARM_RESET = 64;    // cold restart period: bounds the orthogonality drift of the carried basis
 constexpr int PSD_MAX_PAIRS = 512;    // supports k <= 1024
+// -DSCSAMD_PSD_CLOCKS (scripts/build_variant.sh): cone 0 of every launch prints its phase clocks (clock64: shader clock) and step counts
+// -- the measurement behind profiles/r5_psd_pipelined_step.md; compiled out of every shipped library
+#ifdef SCSAMD_PSD_CLOCKS
+#define PSD_CLK(v) const long long v = clock64()
+#define PSD_COUNT(x) ++(x)
+#else
+#define PSD_CLK(v)
+#define PSD_COUNT(x)
+#endif
+constexpr int PSD_TBL = 256;          // second rotation-table buffer of the pipelined step (LDS path: <= 46 pairs)
+constexpr int PSD_PIPE_THREADS = PSD_THREADS - 64; // update lanes of the pipelined step (the last wave looks ahead)
 constexpr int PSD_K_LIMIT = 2 * PSD_MAX_PAIRS;
 constexpr size_t PSD_LDS_HEADER = PSD_MAX_PAIRS * (2 * sizeof(real) + 2 * sizeof(int)) + 10 * sizeof(real);
 
@@ -324,10 +336,6 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_soc_tile_apply(real *x, const 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #endif
 
-struct alignas(2 * sizeof(real)) RotCS {
-  real c, s;
-};
-
 // packed lower triangle, column major: column j starts at j*k - j*(j-1)/2
 __device__ __forceinline__ int packed_index(int i, int j, int k) { // i >= j
   return j * k - (j * (j - 1)) / 2 + (i - j);
@@ -396,114 +404,13 @@ __device__ __forceinline__ real psd_unpack_entry(const real *X, int k, bool cplx
   return v;
 }
 
-// (c, s) of the Jacobi rotation that annihilates a_pq: t = sgn(d) b / (|d| + h), h = sqrt(d^2 + b^2), d = a_qq - a_pp, b = 2 a_pq,
-// c = 1 / sqrt(1 + t^2), s = t c.  Written through the identities (|d| + h)^2 + b^2 = 2 h (|d| + h) and c^2 = (h + |d|) / (2 h):
-//     q = 1 / h = rsqrt(d^2 + b^2),  u = 1/2 + |d| q / 2 = c^2,  rc = rsqrt(u),  c = u rc,  s = sgn(d) b q rc / 2
-// -- two reciprocal square roots instead of a square root, a division and a reciprocal square root in sequence: on this part each of
-// them is a Newton sequence, and the chain sits on 25 - 32 lanes between two barriers of every Jacobi step.  c^2 + s^2 = 1 holds to
-// rounding as before.  Outside the range where d^2 + b^2 is a normal number the sequential form is kept.
-__device__ __forceinline__ void jacobi_cs(real d, real b, real &c, real &s) {
-  const real g = d * d + b * b;
-  const real lo = sizeof(real) == 8 ? (real)1e-290 : (real)1e-30, hi = sizeof(real) == 8 ? (real)1e290 : (real)1e30;
-  if (g > lo && g < hi) {
-    const real q = rsqrt(g);
-    const real u = (real)0.5 + (real)0.5 * absval(d) * q;
-    const real rc = rsqrt(u);
-    c = u * rc;
-    s = (d >= 0 ? b : -b) * ((real)0.5 * q * rc);
-  } else {
-    const real h = sqrt(g);
-    const real t = (d >= 0 ? b : -b) / (absval(d) + h);
-    c = rsqrt(t * t + (real)1);
-    s = t * c;
-  }
-}
-
-// One update pass of the LDS Jacobi kernel, A <- J' A J over 2x2 blocks (rows of pair P, columns of pair Q) and V <- V J over
-// (row, pair) items (there are exactly twice as many of those): every lane owns up to NB blocks and 2 NB row pairs and asks for all
-// its tables, then all its operands, before it computes -- the LDS round trips of a lane's items overlap instead of queueing behind
-// each other.  Items beyond the end are clamped to item 0 for the loads and skipped by the stores (no per-item branches in the
-// load phase).  Same arithmetic as the one-item-at-a-time loop it replaces.
-template <int NB>
-__device__ __forceinline__ void psd_update_pass(real *A, real *V, const int2 *rot_pq, const RotCS *rot_cs, int npairs, int K2, int ld,
-                                                int tid) {
-  constexpr int NV = 2 * NB;
-  const int nblk = npairs * npairs, nv = 2 * nblk; // K2 * npairs == 2 * npairs^2
-  int i11[NB], i12[NB], i21[NB], i22[NB];
-  RotCS r1[NB], r2[NB];
-  bool okb[NB], own[NB];
-#pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    const int e = tid + u * PSD_THREADS;
-    okb[u] = e < nblk;
-    const int ec = okb[u] ? e : 0;
-    // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> distinct LDS banks); the column pair is uniform across
-    // most of a wave
-    const int Q = ec / npairs, P = ec % npairs;
-    const int2 pq1 = rot_pq[P], pq2 = rot_pq[Q];
-    r1[u] = rot_cs[P];
-    r2[u] = rot_cs[Q];
-    i11[u] = pq1.x * ld + pq2.x;
-    i12[u] = pq1.x * ld + pq2.y;
-    i21[u] = pq1.y * ld + pq2.x;
-    i22[u] = pq1.y * ld + pq2.y;
-    // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is left otherwise is
-    // rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the convergence threshold and kept
-    // the sweeps going to the cap)
-    own[u] = P == Q && r1[u].s != (real)0;
-  }
-  int ip[NV], iq[NV];
-  RotCS rq[NV];
-  bool okv[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const int f = tid + j * PSD_THREADS;
-    okv[j] = f < nv;
-    const int fc = okv[j] ? f : 0;
-    const int Q = fc / K2, i = fc % K2; // consecutive rows: stride ld
-    const int2 pq2 = rot_pq[Q];
-    rq[j] = rot_cs[Q];
-    ip[j] = i * ld + pq2.x;
-    iq[j] = i * ld + pq2.y;
-  }
-  real a11[NB], a12[NB], a21[NB], a22[NB], vp[NV], vq[NV];
-#pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    a11[u] = A[i11[u]];
-    a12[u] = A[i12[u]];
-    a21[u] = A[i21[u]];
-    a22[u] = A[i22[u]];
-  }
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    vp[j] = V[ip[j]];
-    vq[j] = V[iq[j]];
-  }
-#pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    if (okb[u]) {
-      const real c1 = r1[u].c, s1 = r1[u].s, c2 = r2[u].c, s2 = r2[u].s;
-      const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
-      const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
-      A[i11[u]] = c2 * r11 - s2 * r12;
-      A[i12[u]] = own[u] ? (real)0 : s2 * r11 + c2 * r12;
-      A[i21[u]] = own[u] ? (real)0 : c2 * r21 - s2 * r22;
-      A[i22[u]] = s2 * r21 + c2 * r22;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    if (okv[j]) {
-      V[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
-      V[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
-    }
-  }
-}
-
 // vprev (nullable): per cone a K2m x ldm eigenbasis carried from the previous projection.  With
 // warm != 0 the iteration starts from A' = Vp' A Vp (nearly diagonal when consecutive ADMM
 // iterates are close) and V = Vp, so it needs 1-2 sweeps instead of ~8; the basis is written back
 // whenever vprev is given.  The host restarts cold every PSD_WARM_RESET calls.
+// PIPE: the pipelined step (round 5) for launches whose largest block leaves room for a second copy of A (order <= PSD_WARM_KMAX);
+// its own instantiation, so that the five-blocks-per-lane update of orders up to 92 does not set this one's register budget
+template <bool PIPE>
 __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *__restrict__ psd_off,
                                                             const int *__restrict__ psd_k, real *scratch,
                                                             int kmax, int lds_kmax, int *status, real *vprev,
@@ -542,11 +449,16 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   if (!use_lds) return; // larger blocks: psd_big.h (chip-wide steps)
   real *A = lds_mat;
   real *V = A + (size_t)K2 * ld;
+  real *Acur = A; // the pipelined step ping-pongs between A and a second copy behind V
   // element (r, c): in LDS row-major with an odd leading dimension (lanes that walk rows hit distinct banks); in the
   // global-memory scratch of large blocks column-major, so the same lanes touch consecutive addresses (the 2x2-block
   // pass and the eigenvector update walk rows -- row-major there cost a 128-byte line per 8-byte access)
   auto MI = [&](int r, int c) { return use_lds ? r * ld + c : c * ld + r; };
   const real sqrt2 = sqrt((real)2);
+  PSD_CLK(clk0);
+#ifdef SCSAMD_PSD_CLOCKS
+  int n_steps = 0, n_rot_steps = 0;
+#endif
   // unpack: full symmetric, diagonal * sqrt(2)  (cones.c:1018-1025)
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
     const int i = e % K2, j = e / K2;
@@ -581,6 +493,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     }
     __syncthreads();
   }
+  PSD_CLK(clk1);
   real fro = 0;
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
     const real v = A[MI(e % K2, e / K2)];
@@ -588,6 +501,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   }
   fro = sqrt(block_sum(fro, red));
   const real eps = sizeof(real) == 8 ? (real)1e-15 : (real)1e-7;
+  PSD_CLK(clk2);
   int sweep = 0;
   if (fro > (real)0) {
     // an off-diagonal entry at or below the convergence threshold is left alone; a step
@@ -598,6 +512,12 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     const real thr = sizeof(real) == 8 ? eps * fro / (real)k : fmaxf(eps * fro / (real)k, (real)2.4e-7 * fro);
     if (tid < 2) rot_any[tid] = 0;
     __syncthreads();
+    // pipelined step: needs a second copy of A (the warm start's T region behind V, dead by now) -> orders up to PSD_WARM_KMAX of a
+    // launch whose largest LDS block is that small (the host sizes the LDS for three matrices then); K2 = 2 has a single step
+    const bool pipelined = PIPE && K2 <= PSD_WARM_KMAX && K2 >= 4;
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool la = wave == PSD_THREADS / 64 - 1; // the look-ahead wave
+    real *A2 = V + (size_t)K2 * ld;
     for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
       // (round 4) a sweep that would rotate nothing is not run: one pass over the off-diagonal entries instead of K2 - 1 steps of pair
       // scans.  The warm-started iteration of consecutive ADMM iterates ends with exactly such a verifying sweep; skipping it leaves the
@@ -607,7 +527,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
           const int i = e / K2, j = e % K2;
           if (i < j && j < k) {
-            const real v = absval(A[MI(i, j)]);
+            const real v = absval(Acur[MI(i, j)]);
             m = v > m ? v : m;
           }
         }
@@ -615,6 +535,63 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         if (m <= thr) break;
       }
       real offmax = 0;
+      if (pipelined) {
+        // ---- pipelined step (round 5; psd_lds_step.h): the last wave forms step s+1's rotations from step s's tables and the matrix
+        // as it stands BEFORE step s, while the other seven waves apply step s from A[cur] into the other copy -- ONE barrier per step
+        // instead of two, and the rotation chain (two rsqrt sequences on <= 36 lanes) off the critical path
+        int pos_a = lane, pos_b = K2 - 1 - lane; // step 0 (lane = pair index in the look-ahead wave)
+        if (la) { // prologue: step 0 from the matrix as it stands
+          bool rot = false;
+          if (lane < npairs) {
+            int2 pq;
+            RotCS cs;
+            rot = psd_first_rotation(Acur, pos_a, pos_b, ld, k, thr, offmax, pq, cs);
+            psd_pair_advance(lane, K2, pos_a, pos_b);
+            rot_pq[lane] = pq;
+            rot_cs[lane] = cs;
+          }
+          const int any = __any(rot ? 1 : 0);
+          if (lane == 0) rot_any[0] = any;
+        }
+        __syncthreads();
+        for (int step = 0; step < K2 - 1; ++step) {
+          const int par = step & 1;
+          const int2 *tq = rot_pq + par * PSD_TBL;
+          const RotCS *tc = rot_cs + par * PSD_TBL;
+          const bool rotates = rot_any[par] != 0; // uniform
+          real *Anext = Acur == A ? A2 : A;
+          if (la) {
+            if (step + 1 < K2 - 1) {
+              bool rot = false;
+              if (lane < npairs) {
+                int2 pq;
+                RotCS cs;
+                rot = psd_lookahead(Acur, tq, tc, lane, npairs, pos_a, pos_b, ld, k, thr, offmax, pq, cs);
+                psd_pair_advance(lane, K2, pos_a, pos_b);
+                rot_pq[(par ^ 1) * PSD_TBL + lane] = pq;
+                rot_cs[(par ^ 1) * PSD_TBL + lane] = cs;
+              }
+              const int any = __any(rot ? 1 : 0);
+              if (lane == 0) rot_any[par ^ 1] = any;
+            }
+          } else if (rotates) {
+            switch ((npairs * npairs + PSD_PIPE_THREADS - 1) / PSD_PIPE_THREADS) { // blocks per lane (K2 <= 72: at most 3)
+            case 1: psd_update_pass<1>(Acur, Anext, V, tq, tc, npairs, K2, ld, tid, PSD_PIPE_THREADS); break;
+            case 2: psd_update_pass<2>(Acur, Anext, V, tq, tc, npairs, K2, ld, tid, PSD_PIPE_THREADS); break;
+            default: psd_update_pass<3>(Acur, Anext, V, tq, tc, npairs, K2, ld, tid, PSD_PIPE_THREADS); break;
+            }
+          }
+          __syncthreads();
+          PSD_COUNT(n_steps);
+          if (rotates) {
+            Acur = Anext;
+            PSD_COUNT(n_rot_steps);
+          }
+        }
+        offmax = block_max(offmax, red);
+        if (offmax <= thr) break;
+        continue;
+      }
       // round-robin pairing: player 0 fixed, the others rotate -- pair i of step s is (0 or 1 + (i - 1 + s) mod (K2 - 1),
       // 1 + (K2 - 2 - i + s) mod (K2 - 1)); the two positions advance by one per step (no run-time modulus on the step's critical path)
       int pos_a = tid, pos_b = K2 - 1 - tid; // step 0 (for tid < npairs: i - 1 < K2 - 1 and K2 - 2 - i >= 0)
@@ -646,15 +623,20 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
           if (i == 0) rot_any[par ^ 1] = 0; // nobody reads the other parity before the next step's barrier
         }
         __syncthreads();
+        PSD_COUNT(n_steps);
         if (!rot_any[par]) continue; // uniform: every pair of this step is already converged
+        PSD_COUNT(n_rot_steps);
         // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q);
         // V <- V J over (row, pair) items.  One barrier per step for both.
+        if (PIPE) { // only K2 = 2 comes here in the pipelined instantiation
+          psd_update_pass<1>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS);
+        } else
         switch ((npairs * npairs + PSD_THREADS - 1) / PSD_THREADS) { // blocks per lane (uniform over the workgroup)
-        case 1: psd_update_pass<1>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
-        case 2: psd_update_pass<2>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
-        case 3: psd_update_pass<3>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
-        case 4: psd_update_pass<4>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break;
-        default: psd_update_pass<5>(A, V, rot_pq, rot_cs, npairs, K2, ld, tid); break; // K2 <= 92: 46^2 = 2116 <= 5 * 512
+        case 1: psd_update_pass<1>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
+        case 2: psd_update_pass<2>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
+        case 3: psd_update_pass<3>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
+        case 4: psd_update_pass<4>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
+        default: psd_update_pass<5>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break; // K2 <= 92: 46^2 = 2116 <= 5 * 512
         }
         __syncthreads();
       }
@@ -662,8 +644,10 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       if (offmax <= thr) break;
     }
   }
+  PSD_CLK(clk3);
   if (sweep >= PSD_MAX_SWEEPS && tid == 0) atomicAdd(status, 1); // did not converge: counted, not fatal (cones.c:1031-1032)
   // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044); lambda = diag(A)
+  A = Acur;
   __syncthreads();
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
     const int i = use_lds ? e / K2 : e % K2, cidx = use_lds ? e % K2 : e / K2;
@@ -739,6 +723,12 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       X[e] = acc;
     }
   }
+#endif
+#ifdef SCSAMD_PSD_CLOCKS
+  __syncthreads();
+  if (cone == 0 && tid == 0)
+    printf("PSDCLK pipe %d k %d unpack_warm %lld fro %lld sweeps %lld tail %lld nsweep %d steps %d rot_steps %d\n", PIPE ? 1 : 0, k, clk1 - clk0,
+           clk2 - clk1, clk3 - clk2, (long long)clock64() - clk3, sweep, n_steps, n_rot_steps);
 #endif
 }
 
@@ -984,14 +974,20 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
     const int lds_kmax = std::min(psd_kmax, psd_lds_kmax); // largest block order held in LDS
     const int K2l = (lds_kmax + 1) & ~1;
     const bool carry = psd_vprev.p != nullptr;
-    const size_t lds = PSD_LDS_HEADER + (size_t)(carry && !psd_tscratch.p ? 3 : 2) * K2l * (K2l | 1) * sizeof(real);
+    // round 5: pipelined step (second copy of A in LDS) whenever three matrices fit; SCS_AMD_PSD_PIPE=0 keeps the two-phase step (A/B)
+    static const bool pipe_env = [] { const char *e = getenv("SCS_AMD_PSD_PIPE"); return !e || atoi(e) != 0; }();
+    const int pipe = (pipe_env && K2l <= PSD_WARM_KMAX) ? 1 : 0;
+    const size_t lds = PSD_LDS_HEADER + (size_t)((pipe || (carry && !psd_tscratch.p)) ? 3 : 2) * K2l * (K2l | 1) * sizeof(real);
     const int warm = carry && (psd_calls % PSD_WARM_RESET) != 0;
     ++psd_calls;
-    if (lds > 48 * 1024)
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_psd_jacobi),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_psd_jacobi, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p,
-                       psd_tscratch.p, lds_kmax, lds_kmax, status.p, psd_vprev.p, warm);
+    auto launch = [&](auto kern) {
+      if (lds > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p, psd_tscratch.p, lds_kmax, lds_kmax,
+                         status.p, psd_vprev.p, warm);
+    };
+    if (pipe) launch(k_psd_jacobi<true>);
+    else launch(k_psd_jacobi<false>);
     if (psd_big) psd_big->project(cw, psd_off.p, psd_k.p, status.p, stream);
   }
   proj_exp_pow(cw);

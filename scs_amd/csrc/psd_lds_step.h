@@ -1,0 +1,215 @@
+// psd_lds_step.h -- the lane-level pieces of ONE round-robin step of the LDS Jacobi kernel (k_psd_jacobi, cones.hip):
+// rotation parameters, the 2x2-block update pass, and (round 5) the LOOK-AHEAD that forms step s+1's rotations while step s
+// is still being applied.  Replaces the eigen-decomposition behind reference src/cones.c:999-1067 (LAPACK dsyevr).
+//
+// The same functions compile for the host (PSD_STEP_HOST_CHECK, tests/native/host_check_psd_step.cpp: lanes looped one at a
+// time, a barrier = the end of a loop), so the schedule -- which pair feeds which, the ping-pong of A, the table parities --
+// is pinned on the CPU against numpy's eigh and against the un-pipelined order without a GPU.
+//
+// Pipelined step (orders K2 <= PSD_WARM_KMAX, where a second copy of A fits LDS beside A and V):
+//   tables[t & 1]   = (p, q, c, s) of every pair of step t;  rot_any[t & 1] = does step t rotate at all
+//   phase s (ONE barrier per step instead of two):
+//     update lanes    read  A[cur], tables[s & 1];  write A[cur ^ 1] (all of it) and V in place      -- only if rot_any[s & 1]
+//     look-ahead lanes (their own wave) read A[cur], tables[s & 1]; apply step s's rotations to just the three entries
+//                     a_pq, a_pp, a_qq their pair of step s+1 needs; write tables[(s+1) & 1], rot_any[(s+1) & 1]
+//   barrier;  cur ^= rot_any[s & 1]
+// Circle method: pair i of step s+1 takes its first player from pair i+1 of step s (pair 0 keeps player 0; the last pair takes
+// the OTHER player of itself) and its second player from pair i-1 (pair 0: from pair 1) -- so the look-ahead lane knows which two
+// table rows to read without an inverse table.
+#pragma once
+
+#ifdef PSD_STEP_HOST_CHECK
+#define PSD_HD inline
+#define PSD_UNROLL
+struct PsdPair {
+  int x, y;
+};
+#else
+#define PSD_HD __device__ __forceinline__
+#define PSD_UNROLL _Pragma("unroll")
+typedef int2 PsdPair;
+#endif
+
+namespace scsamd {
+
+struct alignas(2 * sizeof(real)) RotCS {
+  real c, s;
+};
+
+PSD_HD real psd_abs(real x) { return x < 0 ? -x : x; }
+
+// (c, s) of the Jacobi rotation that annihilates a_pq: t = sgn(d) b / (|d| + h), h = sqrt(d^2 + b^2), d = a_qq - a_pp, b = 2 a_pq,
+// c = 1 / sqrt(1 + t^2), s = t c.  Written through the identities (|d| + h)^2 + b^2 = 2 h (|d| + h) and c^2 = (h + |d|) / (2 h):
+//     q = 1 / h = rsqrt(d^2 + b^2),  u = 1/2 + |d| q / 2 = c^2,  rc = rsqrt(u),  c = u rc,  s = sgn(d) b q rc / 2
+// -- two reciprocal square roots instead of a square root, a division and a reciprocal square root in sequence: on this part each of
+// them is a Newton sequence, and the chain sits on the critical path of every Jacobi step.  c^2 + s^2 = 1 holds to
+// rounding as before.  Outside the range where d^2 + b^2 is a normal number the sequential form is kept.
+PSD_HD void jacobi_cs(real d, real b, real &c, real &s) {
+  const real g = d * d + b * b;
+  const real lo = sizeof(real) == 8 ? (real)1e-290 : (real)1e-30, hi = sizeof(real) == 8 ? (real)1e290 : (real)1e30;
+  if (g > lo && g < hi) {
+    const real q = rsqrt(g);
+    const real u = (real)0.5 + (real)0.5 * psd_abs(d) * q;
+    const real rc = rsqrt(u);
+    c = u * rc;
+    s = (d >= 0 ? b : -b) * ((real)0.5 * q * rc);
+  } else {
+    const real h = sqrt(g);
+    const real t = (d >= 0 ? b : -b) / (psd_abs(d) + h);
+    c = rsqrt(t * t + (real)1);
+    s = t * c;
+  }
+}
+
+// One update pass, A_dst <- J' A_src J over 2x2 blocks (rows of pair P, columns of pair Q) and V <- V J over (row, pair) items (there
+// are exactly twice as many of those): every lane owns up to NB blocks and 2 NB row pairs and asks for all its tables, then all its
+// operands, before it computes -- the LDS round trips of a lane's items overlap instead of queueing behind each other.  Items beyond
+// the end are clamped to item 0 for the loads and skipped by the stores (no per-item branches in the load phase).  A_dst == A_src
+// is the in-place form of rounds 2-4 (every entry is read and written by the same lane); the pipelined step passes the other copy.
+// nthreads = lanes taking part (tid < nthreads).
+template <int NB>
+PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, int npairs, int K2, int ld,
+                            int tid, int nthreads) {
+  constexpr int NV = 2 * NB;
+  const int nblk = npairs * npairs, nv = 2 * nblk; // K2 * npairs == 2 * npairs^2
+  int i11[NB], i12[NB], i21[NB], i22[NB];
+  RotCS r1[NB], r2[NB];
+  bool okb[NB], own[NB];
+  PSD_UNROLL
+  for (int u = 0; u < NB; ++u) {
+    const int e = tid + u * nthreads;
+    okb[u] = e < nblk;
+    const int ec = okb[u] ? e : 0;
+    // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> distinct LDS banks); the column pair is uniform across
+    // most of a wave
+    const int Q = ec / npairs, P = ec % npairs;
+    const PsdPair pq1 = rot_pq[P], pq2 = rot_pq[Q];
+    r1[u] = rot_cs[P];
+    r2[u] = rot_cs[Q];
+    i11[u] = pq1.x * ld + pq2.x;
+    i12[u] = pq1.x * ld + pq2.y;
+    i21[u] = pq1.y * ld + pq2.x;
+    i22[u] = pq1.y * ld + pq2.y;
+    // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is left otherwise is
+    // rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the convergence threshold and kept
+    // the sweeps going to the cap)
+    own[u] = P == Q && r1[u].s != (real)0;
+  }
+  int ip[NV], iq[NV];
+  RotCS rq[NV];
+  bool okv[NV];
+  PSD_UNROLL
+  for (int j = 0; j < NV; ++j) {
+    const int f = tid + j * nthreads;
+    okv[j] = f < nv;
+    const int fc = okv[j] ? f : 0;
+    const int Q = fc / K2, i = fc % K2; // consecutive rows: stride ld
+    const PsdPair pq2 = rot_pq[Q];
+    rq[j] = rot_cs[Q];
+    ip[j] = i * ld + pq2.x;
+    iq[j] = i * ld + pq2.y;
+  }
+  real a11[NB], a12[NB], a21[NB], a22[NB], vp[NV], vq[NV];
+  PSD_UNROLL
+  for (int u = 0; u < NB; ++u) {
+    a11[u] = Asrc[i11[u]];
+    a12[u] = Asrc[i12[u]];
+    a21[u] = Asrc[i21[u]];
+    a22[u] = Asrc[i22[u]];
+  }
+  PSD_UNROLL
+  for (int j = 0; j < NV; ++j) {
+    vp[j] = V[ip[j]];
+    vq[j] = V[iq[j]];
+  }
+  PSD_UNROLL
+  for (int u = 0; u < NB; ++u) {
+    if (okb[u]) {
+      const real c1 = r1[u].c, s1 = r1[u].s, c2 = r2[u].c, s2 = r2[u].s;
+      const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
+      const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
+      Adst[i11[u]] = c2 * r11 - s2 * r12;
+      Adst[i12[u]] = own[u] ? (real)0 : s2 * r11 + c2 * r12;
+      Adst[i21[u]] = own[u] ? (real)0 : c2 * r21 - s2 * r22;
+      Adst[i22[u]] = s2 * r21 + c2 * r22;
+    }
+  }
+  PSD_UNROLL
+  for (int j = 0; j < NV; ++j) {
+    if (okv[j]) {
+      V[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
+      V[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
+    }
+  }
+}
+
+// the players of pair i at the round-robin positions (pos_a, pos_b), and the positions of the next step (player 0 never moves;
+// the others advance by one around the K2 - 1 seats)
+PSD_HD void psd_pair_advance(int i, int K2, int &pos_a, int &pos_b) {
+  if (i != 0) pos_a = pos_a == K2 - 1 ? 1 : pos_a + 1;
+  pos_b = pos_b == K2 - 1 ? 1 : pos_b + 1;
+}
+
+// rotation of the pair (lo, hi), lo < hi, from its three entries; entries at or below the threshold -- and the padding index of an
+// odd order -- are left alone (identity).  Returns whether it rotates; tracks the sweep's largest off-diagonal entry.
+PSD_HD bool psd_make_rotation(real apq, real app, real aqq, int hi, int k, real thr, real &offmax, RotCS &cs) {
+  real c = 1, s = 0;
+  const real aa = psd_abs(apq);
+  bool rot = false;
+  if (hi < k) {
+    offmax = aa > offmax ? aa : offmax;
+    if (aa > thr) {
+      jacobi_cs(aqq - app, (real)2 * apq, c, s);
+      rot = true;
+    }
+  }
+  cs = RotCS{c, s};
+  return rot;
+}
+
+// one entry (row side rs, column side cs_) of the 2x2 block J1' [a11 a12; a21 a22] J2 -- the expressions of psd_update_pass
+PSD_HD real psd_block_entry(real a11, real a12, real a21, real a22, const RotCS &r1, const RotCS &r2, int rs, int cs_) {
+  const real ra = rs == 0 ? r1.c * a11 - r1.s * a21 : r1.s * a11 + r1.c * a21; // row rs of J1' A, column 0
+  const real rb = rs == 0 ? r1.c * a12 - r1.s * a22 : r1.s * a12 + r1.c * a22; // column 1
+  return cs_ == 0 ? r2.c * ra - r2.s * rb : r2.s * ra + r2.c * rb;
+}
+
+// Look-ahead of lane i (pair i of step s + 1; (p, q) = its players, any order): reads step s's tables and the matrix as it stands
+// BEFORE step s is applied, returns the rotation of its pair for the matrix AFTER step s.  rot_pq rows are sorted (x < y).
+PSD_HD bool psd_lookahead(const real *A, const PsdPair *rot_pq, const RotCS *rot_cs, int i, int npairs, int p, int q, int ld, int k,
+                          real thr, real &offmax, PsdPair &pq_out, RotCS &cs_out) {
+  const int src_p = i == 0 ? 0 : (i == npairs - 1 ? npairs - 1 : i + 1); // pair of step s that holds p
+  const int src_q = i == 0 ? 1 : i - 1;                                    // ... that holds q
+  const bool swap = p > q;
+  const int lo = swap ? q : p, hi = swap ? p : q;
+  const int Plo = swap ? src_q : src_p, Phi = swap ? src_p : src_q;
+  const PsdPair pl = rot_pq[Plo], ph = rot_pq[Phi];
+  const RotCS rl = rot_cs[Plo], rh = rot_cs[Phi];
+  const int sl = lo == pl.x ? 0 : 1, sh = hi == ph.x ? 0 : 1; // which player of its old pair
+  // the three 2x2 blocks that hold a_lohi, a_lolo, a_hihi: (Plo, Phi), (Plo, Plo), (Phi, Phi) -- twelve independent reads
+  const real b11 = A[pl.x * ld + ph.x], b12 = A[pl.x * ld + ph.y], b21 = A[pl.y * ld + ph.x], b22 = A[pl.y * ld + ph.y];
+  const real l11 = A[pl.x * ld + pl.x], l12 = A[pl.x * ld + pl.y], l21 = A[pl.y * ld + pl.x], l22 = A[pl.y * ld + pl.y];
+  const real h11 = A[ph.x * ld + ph.x], h12 = A[ph.x * ld + ph.y], h21 = A[ph.y * ld + ph.x], h22 = A[ph.y * ld + ph.y];
+  const real apq = psd_block_entry(b11, b12, b21, b22, rl, rh, sl, sh);
+  const real app = psd_block_entry(l11, l12, l21, l22, rl, rl, sl, sl);
+  const real aqq = psd_block_entry(h11, h12, h21, h22, rh, rh, sh, sh);
+  pq_out.x = lo;
+  pq_out.y = hi;
+  return psd_make_rotation(apq, app, aqq, hi, k, thr, offmax, cs_out);
+}
+
+// first step of a sweep: nothing is pending, the three entries are read as they stand
+PSD_HD bool psd_first_rotation(const real *A, int p, int q, int ld, int k, real thr, real &offmax, PsdPair &pq_out, RotCS &cs_out) {
+  const int lo = p > q ? q : p, hi = p > q ? p : q;
+  pq_out.x = lo;
+  pq_out.y = hi;
+  const real apq = A[lo * ld + hi];
+  real app = 0, aqq = 0;
+  if (hi < k && psd_abs(apq) > thr) {
+    app = A[lo * ld + lo];
+    aqq = A[hi * ld + hi];
+  }
+  return psd_make_rotation(apq, app, aqq, hi, k, thr, offmax, cs_out);
+}
+
+} // namespace scsamd
