@@ -25,6 +25,7 @@
 #include "cones.h"
 #include "cones_exp_pow.h"
 #include <algorithm>
+#include <type_traits>
 #include "psd_lds_step.h" // RotCS, jacobi_cs, psd_update_pass, the look-ahead of the pipelined step
 
 namespace scsamd {
@@ -518,27 +519,30 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     const int wave = tid >> 6, lane = tid & 63;
     const bool la = wave == PSD_THREADS / 64 - 1; // the look-ahead wave
     real *A2 = V + (size_t)K2 * ld;
-    for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
-      // (round 4) a sweep that would rotate nothing is not run: one pass over the off-diagonal entries instead of K2 - 1 steps of pair
-      // scans.  The warm-started iteration of consecutive ADMM iterates ends with exactly such a verifying sweep; skipping it leaves the
-      // same A and V (a sweep without rotations changes nothing).
-      {
-        real m = 0;
-        for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
-          const int i = e / K2, j = e % K2;
-          if (i < j && j < k) {
-            const real v = absval(Acur[MI(i, j)]);
-            m = v > m ? v : m;
-          }
+    // (round 4) a sweep that would rotate nothing is not run: one pass over the off-diagonal entries instead of K2 - 1 steps of pair
+    // scans.  The warm-started iteration of consecutive ADMM iterates ends with exactly such a verifying sweep; skipping it leaves the
+    // same A and V (a sweep without rotations changes nothing).
+    auto nothing_to_rotate = [&]() {
+      real m = 0;
+      for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
+        const int i = e / K2, j = e % K2;
+        if (i < j && j < k) {
+          const real v = absval(Acur[MI(i, j)]);
+          m = v > m ? v : m;
         }
-        m = block_max(m, red);
-        if (m <= thr) break;
       }
-      real offmax = 0;
-      if (pipelined) {
-        // ---- pipelined step (round 5; psd_lds_step.h): the last wave forms step s+1's rotations from step s's tables and the matrix
-        // as it stands BEFORE step s, while the other seven waves apply step s from A[cur] into the other copy -- ONE barrier per step
-        // instead of two, and the rotation chain (two rsqrt sequences on <= 36 lanes) off the critical path
+      return block_max(m, red) <= thr;
+    };
+    // ---- pipelined step (round 5; psd_lds_step.h): the last wave forms step s+1's rotations from step s's tables and the matrix as it
+    // stands BEFORE step s, while the other seven waves apply step s from A[cur] into the other copy -- ONE barrier per step instead
+    // of two, and the rotation chain (two rsqrt sequences on <= 36 lanes) off the critical path.  NB = 2x2 blocks per update lane.
+    auto sweeps_pipelined = [&](auto nbc) {
+      constexpr int NB = decltype(nbc)::value;
+      PsdItems<NB> items;
+      psd_items_init<NB>(items, tid, PSD_PIPE_THREADS, npairs, K2); // the lane's blocks and row pairs: once, not per step
+      for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+        if (nothing_to_rotate()) break;
+        real offmax = 0;
         int pos_a = lane, pos_b = K2 - 1 - lane; // step 0 (lane = pair index in the look-ahead wave)
         if (la) { // prologue: step 0 from the matrix as it stands
           bool rot = false;
@@ -574,12 +578,8 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
               const int any = __any(rot ? 1 : 0);
               if (lane == 0) rot_any[par ^ 1] = any;
             }
-          } else if (rotates) {
-            switch ((npairs * npairs + PSD_PIPE_THREADS - 1) / PSD_PIPE_THREADS) { // blocks per lane (K2 <= 72: at most 3)
-            case 1: psd_update_pass<1>(Acur, Anext, V, tq, tc, npairs, K2, ld, tid, PSD_PIPE_THREADS); break;
-            case 2: psd_update_pass<2>(Acur, Anext, V, tq, tc, npairs, K2, ld, tid, PSD_PIPE_THREADS); break;
-            default: psd_update_pass<3>(Acur, Anext, V, tq, tc, npairs, K2, ld, tid, PSD_PIPE_THREADS); break;
-            }
+          } else {
+            psd_update_pass<NB>(Acur, Anext, V, tq, tc, items, ld, rotates); // loads first, `rotates` is only needed for the stores
           }
           __syncthreads();
           PSD_COUNT(n_steps);
@@ -590,58 +590,61 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         }
         offmax = block_max(offmax, red);
         if (offmax <= thr) break;
-        continue;
       }
-      // round-robin pairing: player 0 fixed, the others rotate -- pair i of step s is (0 or 1 + (i - 1 + s) mod (K2 - 1),
-      // 1 + (K2 - 2 - i + s) mod (K2 - 1)); the two positions advance by one per step (no run-time modulus on the step's critical path)
-      int pos_a = tid, pos_b = K2 - 1 - tid; // step 0 (for tid < npairs: i - 1 < K2 - 1 and K2 - 2 - i >= 0)
-      for (int step = 0; step < K2 - 1; ++step) {
-        const int par = step & 1;
-        if (tid < npairs) {
-          const int i = tid;
-          int p = pos_a, q = pos_b;
-          if (i != 0) pos_a = pos_a == K2 - 1 ? 1 : pos_a + 1;
-          pos_b = pos_b == K2 - 1 ? 1 : pos_b + 1;
-          if (p > q) {
-            const int t = p;
-            p = q;
-            q = t;
+    };
+    // ---- two-phase step (rounds 2-4): rotation parameters on the first npairs lanes, barrier, in-place update, barrier.  Orders
+    // 73..92 (no room for a second copy of A) and K2 = 2.
+    // round-robin pairing: player 0 fixed, the others rotate -- pair i of step s is (0 or 1 + (i - 1 + s) mod (K2 - 1),
+    // 1 + (K2 - 2 - i + s) mod (K2 - 1)); the two positions advance by one per step (no run-time modulus on the step's critical path)
+    auto sweeps_two_phase = [&](auto nbc) {
+      constexpr int NB = decltype(nbc)::value;
+      PsdItems<NB> items;
+      psd_items_init<NB>(items, tid, PSD_THREADS, npairs, K2);
+      for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+        if (nothing_to_rotate()) break;
+        real offmax = 0;
+        int pos_a = tid, pos_b = K2 - 1 - tid; // step 0 (for tid < npairs: i - 1 < K2 - 1 and K2 - 2 - i >= 0)
+        for (int step = 0; step < K2 - 1; ++step) {
+          const int par = step & 1;
+          if (tid < npairs) {
+            int2 pq;
+            RotCS cs;
+            // an off-diagonal entry at or below the threshold is left alone (identity); t = sgn(d) b / (|d| + sqrt(d^2 + b^2))
+            if (psd_first_rotation(A, pos_a, pos_b, ld, k, thr, offmax, pq, cs)) rot_any[par] = 1;
+            psd_pair_advance(tid, K2, pos_a, pos_b);
+            rot_pq[tid] = pq;
+            rot_cs[tid] = cs;
+            if (tid == 0) rot_any[par ^ 1] = 0; // nobody reads the other parity before the next step's barrier
           }
-          real c = 1, s = 0;
-          const real apq = A[MI(p, q)];
-          const real aa = absval(apq);
-          if (q < k) offmax = aa > offmax ? aa : offmax;
-          if (q < k && aa > thr) {
-            // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written
-            // without the first division: t = sgn(d) b / (|d| + sqrt(d^2 + b^2)), d = aqq - app, b = 2 apq
-            const real d = A[MI(q, q)] - A[MI(p, p)], b = (real)2 * apq;
-            jacobi_cs(d, b, c, s);
-            rot_any[par] = 1;
-          }
-          rot_pq[i] = make_int2(p, q);
-          rot_cs[i] = RotCS{c, s};
-          if (i == 0) rot_any[par ^ 1] = 0; // nobody reads the other parity before the next step's barrier
+          __syncthreads();
+          PSD_COUNT(n_steps);
+          if (!rot_any[par]) continue; // uniform: every pair of this step is already converged
+          PSD_COUNT(n_rot_steps);
+          // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q); V <- V J over (row, pair) items
+          psd_update_pass<NB>(A, A, V, rot_pq, rot_cs, items, ld);
+          __syncthreads();
         }
-        __syncthreads();
-        PSD_COUNT(n_steps);
-        if (!rot_any[par]) continue; // uniform: every pair of this step is already converged
-        PSD_COUNT(n_rot_steps);
-        // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q);
-        // V <- V J over (row, pair) items.  One barrier per step for both.
-        if (PIPE) { // only K2 = 2 comes here in the pipelined instantiation
-          psd_update_pass<1>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS);
-        } else
-        switch ((npairs * npairs + PSD_THREADS - 1) / PSD_THREADS) { // blocks per lane (uniform over the workgroup)
-        case 1: psd_update_pass<1>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
-        case 2: psd_update_pass<2>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
-        case 3: psd_update_pass<3>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
-        case 4: psd_update_pass<4>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break;
-        default: psd_update_pass<5>(A, A, V, rot_pq, rot_cs, npairs, K2, ld, tid, PSD_THREADS); break; // K2 <= 92: 46^2 = 2116 <= 5 * 512
-        }
-        __syncthreads();
+        offmax = block_max(offmax, red);
+        if (offmax <= thr) break;
       }
-      offmax = block_max(offmax, red);
-      if (offmax <= thr) break;
+    };
+    using std::integral_constant;
+    if (pipelined) {
+      switch ((npairs * npairs + PSD_PIPE_THREADS - 1) / PSD_PIPE_THREADS) { // blocks per update lane (K2 <= 72: at most 3)
+      case 1: sweeps_pipelined(integral_constant<int, 1>()); break;
+      case 2: sweeps_pipelined(integral_constant<int, 2>()); break;
+      default: sweeps_pipelined(integral_constant<int, 3>()); break;
+      }
+    } else if (PIPE) { // only K2 = 2 comes here in the pipelined instantiation
+      sweeps_two_phase(integral_constant<int, 1>());
+    } else {
+      switch ((npairs * npairs + PSD_THREADS - 1) / PSD_THREADS) { // blocks per lane (uniform over the workgroup)
+      case 1: sweeps_two_phase(integral_constant<int, 1>()); break;
+      case 2: sweeps_two_phase(integral_constant<int, 2>()); break;
+      case 3: sweeps_two_phase(integral_constant<int, 3>()); break;
+      case 4: sweeps_two_phase(integral_constant<int, 4>()); break;
+      default: sweeps_two_phase(integral_constant<int, 5>()); break; // K2 <= 92: 46^2 = 2116 <= 5 * 512
+      }
     }
   }
   PSD_CLK(clk3);

@@ -61,31 +61,54 @@ PSD_HD void jacobi_cs(real d, real b, real &c, real &s) {
   }
 }
 
+// The (block, row-pair) items of a lane: which 2x2 blocks (rows of pair P, columns of pair Q) and which (row i, pair Q) items of V
+// it owns.  They do not depend on the step, and forming them takes integer divisions by run-time values (~35 instructions each on
+// this part, six of them per lane): computed ONCE per projection, not once per step (round 5: they were ~840 of a step's clocks).
+template <int NB>
+struct PsdItems {
+  int bP[NB], bQ[NB], vQ[2 * NB], vI[2 * NB];
+  bool okb[NB], okv[2 * NB];
+};
+template <int NB>
+PSD_HD void psd_items_init(PsdItems<NB> &it, int tid, int nthreads, int npairs, int K2) {
+  const int nblk = npairs * npairs, nv = 2 * nblk; // K2 * npairs == 2 * npairs^2
+  PSD_UNROLL
+  for (int u = 0; u < NB; ++u) {
+    const int e = tid + u * nthreads;
+    it.okb[u] = tid < nthreads && e < nblk;
+    const int ec = it.okb[u] ? e : 0;
+    // lanes walk the ROW pairs (consecutive P -> stride ld, odd -> distinct LDS banks); the column pair is uniform across
+    // most of a wave
+    it.bQ[u] = ec / npairs;
+    it.bP[u] = ec % npairs;
+  }
+  PSD_UNROLL
+  for (int j = 0; j < 2 * NB; ++j) {
+    const int f = tid + j * nthreads;
+    it.okv[j] = tid < nthreads && f < nv;
+    const int fc = it.okv[j] ? f : 0;
+    it.vQ[j] = fc / K2;
+    it.vI[j] = fc % K2; // consecutive rows: stride ld
+  }
+}
+
 // One update pass, A_dst <- J' A_src J over 2x2 blocks (rows of pair P, columns of pair Q) and V <- V J over (row, pair) items (there
 // are exactly twice as many of those): every lane owns up to NB blocks and 2 NB row pairs and asks for all its tables, then all its
 // operands, before it computes -- the LDS round trips of a lane's items overlap instead of queueing behind each other.  Items beyond
 // the end are clamped to item 0 for the loads and skipped by the stores (no per-item branches in the load phase).  A_dst == A_src
 // is the in-place form of rounds 2-4 (every entry is read and written by the same lane); the pipelined step passes the other copy.
-// nthreads = lanes taking part (tid < nthreads).
 template <int NB>
-PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, int npairs, int K2, int ld,
-                            int tid, int nthreads) {
+PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB> &it,
+                            int ld, bool rotates = true) {
   constexpr int NV = 2 * NB;
-  const int nblk = npairs * npairs, nv = 2 * nblk; // K2 * npairs == 2 * npairs^2
   int i11[NB], i12[NB], i21[NB], i22[NB];
   RotCS r1[NB], r2[NB];
-  bool okb[NB], own[NB];
+  bool own[NB];
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
-    const int e = tid + u * nthreads;
-    okb[u] = e < nblk;
-    const int ec = okb[u] ? e : 0;
-    // lanes walk the ROW pairs (consecutive p1 -> stride ld, odd -> distinct LDS banks); the column pair is uniform across
-    // most of a wave
-    const int Q = ec / npairs, P = ec % npairs;
-    const PsdPair pq1 = rot_pq[P], pq2 = rot_pq[Q];
-    r1[u] = rot_cs[P];
-    r2[u] = rot_cs[Q];
+    const PsdPair pq1 = rot_pq[it.bP[u]], pq2 = rot_pq[it.bQ[u]];
+    r1[u] = rot_cs[it.bP[u]];
+    r2[u] = rot_cs[it.bQ[u]];
     i11[u] = pq1.x * ld + pq2.x;
     i12[u] = pq1.x * ld + pq2.y;
     i21[u] = pq1.y * ld + pq2.x;
@@ -93,21 +116,16 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
     // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is left otherwise is
     // rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the convergence threshold and kept
     // the sweeps going to the cap)
-    own[u] = P == Q && r1[u].s != (real)0;
+    own[u] = it.bP[u] == it.bQ[u] && r1[u].s != (real)0;
   }
   int ip[NV], iq[NV];
   RotCS rq[NV];
-  bool okv[NV];
   PSD_UNROLL
   for (int j = 0; j < NV; ++j) {
-    const int f = tid + j * nthreads;
-    okv[j] = f < nv;
-    const int fc = okv[j] ? f : 0;
-    const int Q = fc / K2, i = fc % K2; // consecutive rows: stride ld
-    const PsdPair pq2 = rot_pq[Q];
-    rq[j] = rot_cs[Q];
-    ip[j] = i * ld + pq2.x;
-    iq[j] = i * ld + pq2.y;
+    const PsdPair pq2 = rot_pq[it.vQ[j]];
+    rq[j] = rot_cs[it.vQ[j]];
+    ip[j] = it.vI[j] * ld + pq2.x;
+    iq[j] = it.vI[j] * ld + pq2.y;
   }
   real a11[NB], a12[NB], a21[NB], a22[NB], vp[NV], vq[NV];
   PSD_UNROLL
@@ -122,9 +140,12 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
     vp[j] = V[ip[j]];
     vq[j] = V[iq[j]];
   }
+  // (pipelined step: `rotates` comes out of LDS too -- asked for before the tables, needed only here, so that its round trip rides
+  // along with the loads instead of preceding them; a step that rotates nothing stores nothing)
+  if (!rotates) return;
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
-    if (okb[u]) {
+    if (it.okb[u]) {
       const real c1 = r1[u].c, s1 = r1[u].s, c2 = r2[u].c, s2 = r2[u].s;
       const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
       const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
@@ -136,7 +157,7 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
   }
   PSD_UNROLL
   for (int j = 0; j < NV; ++j) {
-    if (okv[j]) {
+    if (it.okv[j]) {
       V[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
       V[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
     }
