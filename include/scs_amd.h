@@ -297,6 +297,9 @@ void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
  * it -- b, c, warm starts and the returned (x, y, s) are mapped at this boundary).  out[0] = 1 if renumbered, out[1], out[2] =
  * distinct 128-byte lines per gathered entry of the A / A' product as given, out[3], out[4] = after, out[5] = seconds spent. */
 void scs_amd_get_reorder_info(const ScsWork *w, double *out);
+/* how scs_init laid out A (out[0..2]) and A' (out[3..5]): wave-owned-rows layout built (0 / 1), built on the device (0 / 1),
+ * distinct 128-byte lines per gathered entry (scs_amd/csrc/spmv_wave.h, spmv_wave_build.h) */
+void scs_amd_get_layout_info(const ScsWork *w, double *out);
 /* Test hook, host code only: the renumbering decision scs_init would take for this matrix and cone (no device needed).
  * col_new2old (n) and row_new2old (m) receive new index -> caller's index (identity when nothing is kept); info (6 doubles, may be
  * NULL) as scs_amd_get_reorder_info.  Returns 1 if a renumbering is kept, 0 if not, < 0 on error. */

@@ -195,6 +195,8 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             lib.scs_amd_plan_reorder.argtypes = [C.POINTER(T.ScsMatrix), C.POINTER(T.ScsCone), T.ip, T.ip, C.POINTER(C.c_double)]
             lib.scs_amd_get_reorder_info.restype = None
             lib.scs_amd_get_reorder_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+            lib.scs_amd_get_layout_info.restype = None
+            lib.scs_amd_get_layout_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
             lib.scs_amd_set_residuals_every_iter.restype = None
             lib.scs_amd_set_residuals_every_iter.argtypes = [C.c_void_p, scs_int]
     lib._scs_types = T

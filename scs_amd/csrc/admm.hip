@@ -1174,7 +1174,7 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     CscView Av = w->A.view(), Pv{nullptr, nullptr, nullptr, 0, 0};
     if (w->has_P) Pv = w->P.view();
     w->ls.init(&Av, w->has_P ? &Pv : nullptr, w->stream, &a_pattern);
-    a_pattern = CsrPattern();
+    a_pattern.clear();
     phase("linsys init");
     set_diag_r(w);
     w->ls.set_diag_r_dev(w->diag_r.p);
@@ -1515,6 +1515,19 @@ void scs_amd_get_reorder_info(const ScsWork *w, double *out) {
   out[3] = w->reord.after[0];
   out[4] = w->reord.after[1];
   out[5] = w->reord.seconds;
+}
+
+// how scs_init laid the matrices out (spmv_wave.h / spmv_wave_build.h): for A then A': out[0], out[3] = wave-owned-rows layout built
+// (0 / 1), out[1], out[4] = built on the device (0 / 1), out[2], out[5] = distinct 128-byte lines per gathered entry
+void scs_amd_get_layout_info(const ScsWork *w, double *out) {
+  if (!w || !out) return;
+  const WaveRowsDev *wv[2] = {w->ls.A.wave, w->ls.At.wave};
+  for (int i = 0; i < 2; ++i) {
+    const bool b = wv[i] && wv[i]->built;
+    out[3 * i] = b ? 1 : 0;
+    out[3 * i + 1] = b && wv[i]->built_on_device ? 1 : 0;
+    out[3 * i + 2] = b ? wv[i]->lines_per_entry : 0;
+  }
 }
 
 // test hook (host only, no HIP call): the decision of reorder.h on a caller's matrix.  col_new2old (n) / row_new2old (m) receive the

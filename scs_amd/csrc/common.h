@@ -86,6 +86,14 @@ template <typename T> struct DevBuf {
   explicit DevBuf(size_t count) { alloc(count); }
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
+  // ownership can be handed on (setup hands matrices that are already in HBM to the solver instead of re-uploading them)
+  void take(DevBuf &o) {
+    release();
+    p = o.p;
+    n = o.n;
+    o.p = nullptr;
+    o.n = 0;
+  }
   ~DevBuf() { release(); }
   void alloc(size_t count) {
     release();

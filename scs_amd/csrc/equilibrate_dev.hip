@@ -133,6 +133,71 @@ k_gather(const real *__restrict__ src, const int *__restrict__ map, real *__rest
 
 inline int grid_for(long long items) { return std::max(1, ceil_div(items, SCSAMD_BLOCK)); }
 
+// ---- pattern transpose on the device (round 5; the host loop below stays as the general path and the oracle:
+// SCS_AMD_TRANSPOSE = dev | host | verify).  Bit-identical to the host's counting sort: row counts by integer atomics (order free),
+// prefix sum on the host (the row pointers are needed there anyway), every entry takes SOME slot of its row by an atomic, then each
+// row's slots -- which hold CSC positions -- are sorted ascending: CSC position order inside a row IS ascending-column order with
+// duplicates in storage order, exactly what the host loop produces.
+constexpr int TR_SHORT = 32;      // rows up to this many entries: one lane sorts the row (insertion sort)
+constexpr int TR_LONG_MAX = 4096; // longer rows: one workgroup, bitonic sort in LDS; beyond this the host builds the pattern
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_count(const int *__restrict__ ci, long long nnz, int *cnt) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nnz) atomicAdd(&cnt[ci[q] + 1], 1);
+}
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_scatter(const int *__restrict__ ci, long long nnz, int *nxt, int *rpos) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nnz) rpos[atomicAdd(&nxt[ci[q]], 1)] = (int)q;
+}
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_short(const int *__restrict__ rp, int rows, int *rpos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const int a = rp[i], len = rp[i + 1] - a;
+  if (len < 2 || len > TR_SHORT) return;
+  for (int u = 1; u < len; ++u) {
+    const int v = rpos[a + u];
+    int w = u - 1;
+    while (w >= 0 && rpos[a + w] > v) {
+      rpos[a + w + 1] = rpos[a + w];
+      --w;
+    }
+    rpos[a + w + 1] = v;
+  }
+}
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_long(const int *__restrict__ rp, const int *__restrict__ rows_long, int *rpos) {
+  __shared__ int key[TR_LONG_MAX];
+  const int i = rows_long[blockIdx.x], a = rp[i], len = rp[i + 1] - a, tid = threadIdx.x;
+  int P2 = 64;
+  while (P2 < len) P2 <<= 1;
+  for (int t = tid; t < P2; t += SCSAMD_BLOCK) key[t] = t < len ? rpos[a + t] : 0x7fffffff;
+  __syncthreads();
+  for (int k = 2; k <= P2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = tid; e < P2; e += SCSAMD_BLOCK) {
+        const int x = e ^ j;
+        if (x > e) {
+          const bool asc = (e & k) == 0;
+          const int va = key[e], vb = key[x];
+          if ((va > vb) == asc) {
+            key[e] = vb;
+            key[x] = va;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int t = tid; t < len; t += SCSAMD_BLOCK) rpos[a + t] = key[t];
+}
+// the column of every CSC entry, then the CSR column indices through the position map
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_expand_cols(const int *__restrict__ cp, int cols, int *colidx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  for (int q = cp[j]; q < cp[j + 1]; ++q) colidx[q] = j;
+}
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_gather_int(const int *__restrict__ src, const int *__restrict__ map, int *__restrict__ dst, long long len) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < len) dst[k] = src[map[k]];
+}
+
 } // namespace
 
 // A (and P) are the workspace's host CSC copies: their values are replaced by the
@@ -148,23 +213,83 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
   sc.E.assign((size_t)n, (real)1);
   sc.primal_scale = sc.dual_scale = 1;
 
-  // ---- pattern transpose on the host (counting sort; columns ascending inside each row)
   CsrPattern local;
   CsrPattern &R = csr_cache ? *csr_cache : local;
-  R.rp.assign((size_t)m + 1, 0);
-  R.rj.resize((size_t)nnz);
-  R.pos.resize((size_t)nnz);
-  for (long long q = 0; q < nnz; ++q) R.rp[(size_t)A.i[q] + 1]++;
-  for (int i = 0; i < m; ++i) R.rp[i + 1] += R.rp[i];
-  {
-    std::vector<int> nxt(R.rp.begin(), R.rp.end() - 1);
+  // ---- the CSC arrays go up first: the pattern transpose below runs on them
+  DevBuf<int> cp((size_t)n + 1), ci((size_t)nnz), rp((size_t)m + 1), rj((size_t)nnz), rpos((size_t)nnz);
+  DevBuf<real> cx((size_t)nnz), rx((size_t)nnz), Dt((size_t)m), Et((size_t)n), D((size_t)m), E((size_t)n);
+  cp.upload(A.p.data(), (size_t)n + 1, st);
+  ci.upload(A.i.data(), (size_t)nnz, st);
+  cx.upload(A.x.data(), (size_t)nnz, st);
+  // ---- pattern transpose: CSR(A) row pointers, column indices and the CSC position of every CSR entry
+  int tr_mode = 1; // device
+  if (const char *e = getenv("SCS_AMD_TRANSPOSE")) tr_mode = !strcmp(e, "host") ? 0 : (!strcmp(e, "verify") ? 2 : 1);
+  auto host_transpose_pattern = [&](CsrPattern &H) { // counting sort; columns ascending inside each row
+    H.rp.assign((size_t)m + 1, 0);
+    H.rj.resize((size_t)nnz);
+    H.pos.resize((size_t)nnz);
+    for (long long q = 0; q < nnz; ++q) H.rp[(size_t)A.i[q] + 1]++;
+    for (int i = 0; i < m; ++i) H.rp[i + 1] += H.rp[i];
+    std::vector<int> nxt(H.rp.begin(), H.rp.end() - 1);
     for (int j = 0; j < n; ++j)
       for (int q = A.p[j]; q < A.p[j + 1]; ++q) {
         const int t = nxt[A.i[q]]++;
-        R.rj[t] = j;
-        R.pos[t] = q;
+        H.rj[t] = j;
+        H.pos[t] = q;
       }
+  };
+  bool tr_on_dev = false;
+  if (tr_mode != 0 && nnz > 0) {
+    const dim3 Bq(SCSAMD_BLOCK);
+    const int gq = grid_for(nnz);
+    hipLaunchKernelGGL(k_tr_count, dim3(gq), Bq, 0, st, ci.p, nnz, rp.p); // rp was zero-filled by alloc
+    R.rp.assign((size_t)m + 1, 0);
+    rp.download(R.rp.data(), (size_t)m + 1, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    int maxlen = 0;
+    std::vector<int> long_rows;
+    for (int i = 0; i < m; ++i) {
+      const int len = R.rp[i + 1];
+      if (len > TR_SHORT) long_rows.push_back(i);
+      maxlen = std::max(maxlen, len);
+      R.rp[i + 1] += R.rp[i];
+    }
+    if (maxlen <= TR_LONG_MAX) {
+      tr_on_dev = true;
+      rp.upload(R.rp.data(), (size_t)m + 1, st);
+      DevBuf<int> nxt((size_t)m + 1), colidx((size_t)nnz), dlong(long_rows.size() ? long_rows.size() : 1);
+      HIP_CHECK(hipMemcpyAsync(nxt.p, rp.p, (size_t)m * sizeof(int), hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_tr_scatter, dim3(gq), Bq, 0, st, ci.p, nnz, nxt.p, rpos.p);
+      hipLaunchKernelGGL(k_tr_sort_short, dim3(grid_for(m)), Bq, 0, st, rp.p, m, rpos.p);
+      if (!long_rows.empty()) {
+        dlong.upload(long_rows.data(), long_rows.size(), st);
+        hipLaunchKernelGGL(k_tr_sort_long, dim3((unsigned)long_rows.size()), Bq, 0, st, rp.p, dlong.p, rpos.p);
+      }
+      hipLaunchKernelGGL(k_tr_expand_cols, dim3(grid_for(n)), Bq, 0, st, cp.p, n, colidx.p);
+      hipLaunchKernelGGL(k_gather_int, dim3(gq), Bq, 0, st, colidx.p, rpos.p, rj.p, nnz);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(st)); // long_rows, nxt, colidx are locals
+      R.rj.clear();
+      R.pos.clear();
+      if (tr_mode == 2) { // verify against the host loop
+        CsrPattern H;
+        host_transpose_pattern(H);
+        std::vector<int> gj((size_t)nnz), gp((size_t)nnz);
+        rj.download(gj.data(), (size_t)nnz, st);
+        rpos.download(gp.data(), (size_t)nnz, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (H.rp != R.rp || H.rj != gj || H.pos != gp)
+          throw HipError("scs_amd: device-built pattern transpose differs from the host's (SCS_AMD_TRANSPOSE=verify)");
+      }
+    }
   }
+  if (!tr_on_dev) {
+    host_transpose_pattern(R);
+    rp.upload(R.rp.data(), (size_t)m + 1, st);
+    rj.upload(R.rj.data(), (size_t)nnz, st);
+    rpos.upload(R.pos.data(), (size_t)nnz, st);
+  }
+  R.built_on_device = tr_on_dev;
   // ---- full symmetric P pattern with the position of each upper entry
   std::vector<int> fp, fj, fsrc, upos;
   if (P) {
@@ -211,14 +336,6 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
   }
 
   // ---- upload
-  DevBuf<int> cp((size_t)n + 1), ci((size_t)nnz), rp((size_t)m + 1), rj((size_t)nnz), rpos((size_t)nnz);
-  DevBuf<real> cx((size_t)nnz), rx((size_t)nnz), Dt((size_t)m), Et((size_t)n), D((size_t)m), E((size_t)n);
-  cp.upload(A.p.data(), (size_t)n + 1, st);
-  ci.upload(A.i.data(), (size_t)nnz, st);
-  cx.upload(A.x.data(), (size_t)nnz, st);
-  rp.upload(R.rp.data(), (size_t)m + 1, st);
-  rj.upload(R.rj.data(), (size_t)nnz, st);
-  rpos.upload(R.pos.data(), (size_t)nnz, st);
   sc.D.assign((size_t)m, (real)1);
   D.upload(sc.D.data(), (size_t)m, st);
   E.upload(sc.E.data(), (size_t)n, st);
@@ -311,6 +428,17 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(st));
+  if (csr_cache) { // both orientations stay in HBM for LinSys::init (values: bit-identical to gathering the CSC values through the map)
+    DevMatrices &K = csr_cache->dev;
+    K.cp.take(cp);
+    K.ci.take(ci);
+    K.cx.take(cx);
+    K.rp.take(rp);
+    K.rj.take(rj);
+    K.rx.take(rx);
+    K.rpos.take(rpos);
+    K.valid = true;
+  }
 }
 
 } // namespace scsamd

@@ -88,7 +88,8 @@ struct LinSys {
 
   // A, P: host CSC as handed over by the reference (normalized data).
   // `pat` (optional): an already-built pattern transpose of A_csc
-  void init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, const CsrPattern *pat = nullptr);
+  // with pat->dev.valid the matrices are adopted from HBM (device equilibration) instead of uploaded (round 5)
+  void init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, CsrPattern *pat = nullptr);
   // diag_r = [R_x (n); R_y (m)] : host or device source
   void set_diag_r_host(const real *diag_r);
   void set_diag_r_dev(const real *diag_r_dev);

@@ -16,6 +16,7 @@
 // one control block per batch; kernels issued past convergence return at once,
 // so the iterate returned is exactly the first one meeting the tolerance.
 #include "linsys.h"
+#include "spmv_wave_build.h"
 #include <algorithm>
 #include <atomic>
 
@@ -797,7 +798,7 @@ static void host_transpose(int rows_out, int cols_out, const int *Ap, const int 
     }
 }
 
-void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, const CsrPattern *pat) {
+void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, CsrPattern *pat) {
   n = A_csc->n;
   m = A_csc->m;
   if (s) {
@@ -818,35 +819,48 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, con
     if (dbg_t) fprintf(stderr, "[scs_amd linsys init] %-18s %8.1f ms\n", what, t_now() - tp);
     tp = t_now();
   };
-  // CSC(A) is CSR(A'): upload as is
-  At.upload(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
-  phase("upload At");
+  const bool adopt = pat && pat->dev.valid && !pat->rp.empty();
+  // CSC(A) is CSR(A'): upload as is -- or adopt the copy the device equilibration left in HBM
+  if (adopt) At.adopt(n, m, A_csc->p, pat->dev.cp, pat->dev.ci, pat->dev.cx, stream);
+  else At.upload(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+  phase(adopt ? "adopt At" : "upload At");
   if (WaveRowsDev::wanted(m, A_csc->p, n)) {
     At.wave = new WaveRowsDev();
-    At.wave->build(n, m, A_csc->p, A_csc->i, A_csc->x, stream);
+    wave_build(*At.wave, n, m, A_csc->p, A_csc->i, A_csc->x, At, stream);
     phase("wave-rows At");
-    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A' gathers: %.3f distinct lines per entry -> %s stream\n", At.wave->lines_per_entry, At.wave->pipelined ? "pipelined" : "plain");
+    if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A' gathers: %.3f distinct lines per entry -> %s stream; layout built on the %s\n", At.wave->lines_per_entry, At.wave->pipelined ? "pipelined" : "plain", At.wave->built_on_device ? "device" : "host");
   }
-  {
+  if (adopt) { // CSR(A) is in HBM too; its host column indices / values are only fetched if the host layout builder needs them
+    A.adopt(m, n, pat->rp.data(), pat->dev.rp, pat->dev.rj, pat->dev.rx, stream);
+    pat->dev.valid = false;
+    phase("adopt A");
+    if (WaveRowsDev::wanted(n, pat->rp.data(), m)) {
+      A.wave = new WaveRowsDev();
+      wave_build(*A.wave, m, n, pat->rp.data(), pat->rj.empty() ? nullptr : pat->rj.data(), nullptr, A, stream);
+      phase("wave-rows A");
+      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream; layout built on the %s\n", A.wave->lines_per_entry, A.wave->pipelined ? "pipelined" : "plain", A.wave->built_on_device ? "device" : "host");
+    }
+  } else {
     std::vector<int> Cp_own, Ci_own;
     std::vector<real> Cx;
-    if (pat && !pat->empty()) { // values follow the cached pattern: a gather, not a sort
+    const bool have_pat = pat && !pat->empty() && !pat->rj.empty() && !pat->pos.empty();
+    if (have_pat) { // values follow the cached pattern: a gather, not a sort
       const size_t nz = (size_t)A_csc->p[n];
       Cx.resize(nz);
       for (size_t q = 0; q < nz; ++q) Cx[q] = A_csc->x[pat->pos[q]];
     } else {
       host_transpose(m, n, A_csc->p, A_csc->i, A_csc->x, Cp_own, Ci_own, Cx);
     }
-    const std::vector<int> &Cp = (pat && !pat->empty()) ? pat->rp : Cp_own;
-    const std::vector<int> &Ci = (pat && !pat->empty()) ? pat->rj : Ci_own;
+    const std::vector<int> &Cp = have_pat ? pat->rp : Cp_own;
+    const std::vector<int> &Ci = have_pat ? pat->rj : Ci_own;
     phase("transpose");
     A.upload(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
     phase("upload A");
     if (WaveRowsDev::wanted(n, Cp.data(), m)) {
       A.wave = new WaveRowsDev();
-      A.wave->build(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
+      wave_build(*A.wave, m, n, Cp.data(), Ci.data(), Cx.data(), A, stream);
       phase("wave-rows A");
-      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream\n", A.wave->lines_per_entry, A.wave->pipelined ? "pipelined" : "plain");
+      if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream; layout built on the %s\n", A.wave->lines_per_entry, A.wave->pipelined ? "pipelined" : "plain", A.wave->built_on_device ? "device" : "host");
     }
   }
   has_P = P_csc != nullptr;

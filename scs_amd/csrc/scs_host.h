@@ -65,9 +65,29 @@ struct Scaling {
 
 // pattern of the CSR copy of a CSC matrix: row pointers, column indices and, for every
 // CSR entry, its position in the CSC arrays (so values can be gathered, never re-sorted)
+// (round 5) `dev`: both orientations of the equilibrated matrix as equilibrate_dev left them in HBM -- CSC = CSR(A') in cp / ci / cx,
+// CSR(A) in rp / rj / rx -- so that LinSys::init adopts them instead of gathering the values on the host and uploading 2 x 12 B / nnz
+// again.  With `dev.valid` the host copies rj / pos may be empty (the transpose was built on the device): they are fetched on demand.
+struct DevMatrices {
+  DevBuf<int> cp, ci, rp, rj, rpos;
+  DevBuf<real> cx, rx;
+  bool valid = false;
+};
 struct CsrPattern {
   std::vector<int> rp, rj, pos;
+  DevMatrices dev;
+  bool built_on_device = false; // the transpose (rj, pos) was formed on the device: the host copies are empty
   bool empty() const { return rp.empty(); }
+  void clear() {
+    rp = std::vector<int>();
+    rj = std::vector<int>();
+    pos = std::vector<int>();
+    for (DevBuf<int> *b : {&dev.cp, &dev.ci, &dev.rp, &dev.rj, &dev.rpos}) b->release();
+    dev.cx.release();
+    dev.rx.release();
+    dev.valid = false;
+    built_on_device = false;
+  }
 };
 
 std::vector<int> cone_segments(const ScsCone *k);

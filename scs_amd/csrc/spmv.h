@@ -222,10 +222,6 @@ struct CsrDev {
     rows = rows_;
     cols = cols_;
     nnz = hptr[rows_];
-    if (const char *e = getenv("SCS_AMD_SPMV_MAX_GRID")) {
-      int g = atoi(e);
-      if (g >= 1 && g <= SPMV_MAX_GRID) max_grid = g;
-    }
     ptr.alloc((size_t)rows + 1);
     idx.alloc((size_t)nnz);
     val.alloc((size_t)nnz);
@@ -233,6 +229,24 @@ struct CsrDev {
     if (nnz) {
       idx.upload(hidx, (size_t)nnz, s);
       val.upload(hval, (size_t)nnz, s);
+    }
+    build_row_blocks(hptr, s);
+  }
+  // (round 5) CSR arrays that are ALREADY in HBM (left there by the device equilibration): ownership moves here, nothing is copied;
+  // hptr = the host copy of the row pointers (the row-block table is cut from it)
+  void adopt(int rows_, int cols_, const int *hptr, DevBuf<int> &dptr, DevBuf<int> &didx, DevBuf<real> &dval, hipStream_t s) {
+    rows = rows_;
+    cols = cols_;
+    nnz = hptr[rows_];
+    ptr.take(dptr);
+    idx.take(didx);
+    val.take(dval);
+    build_row_blocks(hptr, s);
+  }
+  void build_row_blocks(const int *hptr, hipStream_t s) {
+    if (const char *e = getenv("SCS_AMD_SPMV_MAX_GRID")) {
+      int g = atoi(e);
+      if (g >= 1 && g <= SPMV_MAX_GRID) max_grid = g;
     }
     std::vector<int> rb;
     rb.push_back(0);

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
 
 struct WaveRowsDev {
   bool built = false;
+  bool built_on_device = false; // spmv_wave_build.h filled wrd / val (else fill_host did)
   int pipelined = 0;           // 1: one chunk of stream in flight ahead of the gathers (csr_wave_kernel<.., 1>): matrices whose gathers share lines
   double lines_per_entry = 1;  // distinct 128-byte lines of x a unit touches / its entries, averaged (1 = every gather its own line)
   int rows = 0, cols = 0, nunit = 0, cbits = 0, accrows = 0, cus = 256;
@@ -260,12 +261,23 @@ struct WaveRowsDev {
     if (const char *e = getenv("SCS_AMD_WAVEROWS")) return atoi(e) != 0; // tests force either path
     return (long long)hptr[rows] >= 1000000LL;
   }
-  void build(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval, hipStream_t st) {
+  // ---- layout construction, in three parts (round 5):
+  //   plan       (host, O(rows)):  which kernel flavour, the unit partition by nonzeros, entry offsets of the units
+  //   fill_host  (host, O(nnz)):   the entries of every unit ordered by column bucket (+ the quarter-window chunk order of the lockstep
+  //                                kernel), distinct lines per entry -- rounds 2-4's builder, kept as the general path (units longer
+  //                                than WR_DEV_UNIT_MAX entries) and as the oracle of the device builder (SCS_AMD_WR_BUILD=verify)
+  //   fill_dev   (device):         the same arrays, bit for bit, from the CSR copy already in HBM (spmv_wave_build.h): one workgroup
+  //                                per unit, two in-LDS bitonic sorts on composite keys that reproduce the host's stable orders
+  std::vector<int> ur, us; // host copies of urow / useg (plan)
+  size_t cap = 0;
+  int bshift = 0;
+  long long nnz_all = 0;
+  void plan(int rows_, int cols_, const int *hptr) {
     rows = rows_;
     cols = cols_;
     cbits = col_bits(cols);
     const int rows_cap = (int)std::min<long long>(WR_ROWS_MAX, 1ll << (32 - cbits));
-    const long long nnz_all = hptr[rows];
+    nnz_all = hptr[rows];
     // nonzero budget per unit: ~8 waves per CU on the whole chip (SCS_AMD_WR_NNZ overrides)
     int dev = 0;
     cus = 256;
@@ -290,7 +302,6 @@ struct WaveRowsDev {
     if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
     if (const char *e = getenv("SCS_AMD_WR_NNZ")) budget = std::max(64, atoi(e));
-    std::vector<int> ur, us;
     auto partition = [&](long long bud) {
       ur.clear();
       ur.push_back(0);
@@ -328,13 +339,30 @@ struct WaveRowsDev {
       accrows = std::max(accrows, ur[u + 1] - ur[u]);
     }
     accrows = (accrows + 1) & ~1;
-    const size_t cap = q + 256 + 8; // the last chunk of a unit may read up to 255 entries past its end
+    cap = q + 256 + 8; // the last chunk of a unit may read up to 255 entries past its end
     if (cap >= ((size_t)1 << 31)) throw HipError("scs_amd: matrix too large for 32-bit entry offsets");
-    std::vector<unsigned> hw(cap, 0u);
-    std::vector<real> hv(cap, (real)0);
+    bshift = std::max(0, cbits - 10);
+  }
+  long long max_unit_entries() const {
+    long long mx = 0;
+    for (int u = 0; u < nunit; ++u) mx = std::max<long long>(mx, us[2 * u + 1] - us[2 * u]);
+    return mx;
+  }
+  // the kernel flavour that follows from the measured line sharing (both builders end here)
+  void finish(long long distinct) {
+    lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
+    pipelined = lines_per_entry < 0.8 ? 1 : 0;
+    if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
+    // lockstep: a barrier in front of every gather instruction when every gather is its own line, one per chunk when a unit's
+    // gathers share lines anyway (band of 1024 rows at the headline sizes: 34.0 vs 35.3 us per product; uniformly random: 65.1 vs 62.2)
+    if (ls_bmode < 0) ls_bmode = lines_per_entry < 0.3 ? 1 : 4;
+    built = true;
+  }
+  void fill_host(const int *hptr, const int *hidx, const real *hval, std::vector<unsigned> &hw, std::vector<real> &hv, long long &distinct_total) {
+    hw.assign(cap, 0u);
+    hv.assign(cap, (real)0);
     // stable counting sort of every unit by column bucket (ordering is a locality heuristic: any
     // order gives the same sums up to rounding)
-    const int bshift = std::max(0, cbits - 10);
     std::vector<int> cnt(WR_BUCKETS + 1);
     for (int u = 0; u < nunit; ++u) {
       const int k0 = hptr[ur[u]], k1 = hptr[ur[u + 1]];
@@ -390,23 +418,29 @@ struct WaveRowsDev {
             ++distinct;
           }
         }
-      lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
-      pipelined = lines_per_entry < 0.8 ? 1 : 0;
-      if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
-      // lockstep: a barrier in front of every gather instruction when every gather is its own line, one per chunk when a unit's
-      // gathers share lines anyway (band of 1024 rows at the headline sizes: 34.0 vs 35.3 us per product; uniformly random: 65.1 vs 62.2)
-      if (ls_bmode < 0) ls_bmode = lines_per_entry < 0.3 ? 1 : 4;
+      distinct_total = distinct;
     }
+  }
+  void alloc_and_upload_plan(hipStream_t st) {
     urow.alloc(ur.size());
     useg.alloc(us.size());
-    wrd.alloc(cap);
+    wrd.alloc(cap); // zero-filled: the gaps between units and the tail hold zeros
     val.alloc(cap);
     urow.upload(ur.data(), ur.size(), st);
     useg.upload(us.data(), us.size(), st);
+  }
+  // rounds 2-4's entry point: everything on the host, then uploaded
+  void build(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval, hipStream_t st) {
+    plan(rows_, cols_, hptr);
+    std::vector<unsigned> hw;
+    std::vector<real> hv;
+    long long distinct = 0;
+    fill_host(hptr, hidx, hval, hw, hv, distinct);
+    alloc_and_upload_plan(st);
     wrd.upload(hw.data(), cap, st);
     val.upload(hv.data(), cap, st);
     HIP_CHECK(hipStreamSynchronize(st));
-    built = true;
+    finish(distinct);
   }
 };
 
