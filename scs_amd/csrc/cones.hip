@@ -630,20 +630,17 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     };
     using std::integral_constant;
     if (pipelined) {
-      switch ((npairs * npairs + PSD_PIPE_THREADS - 1) / PSD_PIPE_THREADS) { // blocks per update lane (K2 <= 72: at most 3)
+      switch (psd_blocks_per_lane(npairs, PSD_PIPE_THREADS)) { // blocks of the upper triangle per update lane (K2 <= 72: at most 2)
       case 1: sweeps_pipelined(integral_constant<int, 1>()); break;
-      case 2: sweeps_pipelined(integral_constant<int, 2>()); break;
-      default: sweeps_pipelined(integral_constant<int, 3>()); break;
+      default: sweeps_pipelined(integral_constant<int, 2>()); break;
       }
     } else if (PIPE) { // only K2 = 2 comes here in the pipelined instantiation
       sweeps_two_phase(integral_constant<int, 1>());
     } else {
-      switch ((npairs * npairs + PSD_THREADS - 1) / PSD_THREADS) { // blocks per lane (uniform over the workgroup)
+      switch (psd_blocks_per_lane(npairs, PSD_THREADS)) { // uniform over the workgroup (K2 <= 92: 46 * 47 / 2 = 1081 <= 3 * 512)
       case 1: sweeps_two_phase(integral_constant<int, 1>()); break;
       case 2: sweeps_two_phase(integral_constant<int, 2>()); break;
-      case 3: sweeps_two_phase(integral_constant<int, 3>()); break;
-      case 4: sweeps_two_phase(integral_constant<int, 4>()); break;
-      default: sweeps_two_phase(integral_constant<int, 5>()); break; // K2 <= 92: 46^2 = 2116 <= 5 * 512
+      default: sweeps_two_phase(integral_constant<int, 3>()); break;
       }
     }
   }

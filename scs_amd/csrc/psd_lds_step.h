@@ -61,29 +61,45 @@ PSD_HD void jacobi_cs(real d, real b, real &c, real &s) {
   }
 }
 
-// The (block, row-pair) items of a lane: which 2x2 blocks (rows of pair P, columns of pair Q) and which (row i, pair Q) items of V
-// it owns.  They do not depend on the step, and forming them takes integer divisions by run-time values (~35 instructions each on
-// this part, six of them per lane): computed ONCE per projection, not once per step (round 5: they were ~840 of a step's clocks).
+// The (block, row-pair) items of a lane: which 2x2 blocks (rows of pair P, columns of pair Q, P <= Q) and which (row i, pair Q) items of V
+// it owns.  They do not depend on the step, and forming them takes integer divisions by run-time values: computed ONCE per
+// projection, not once per step.
+//
+// Symmetric storage (round 5): only the entries (r, c) with r <= c of A are kept current -- entry (r, c) lives at min(r, c) * ld +
+// max(r, c) -- so a step updates npairs (npairs + 1) / 2 blocks instead of npairs^2, with half the LDS traffic and half the
+// arithmetic on A, and A stays symmetric by construction (rounds 2-4 computed both triangles, equal only to rounding, and read one).
+// The lower triangle is never read after the warm start.
 template <int NB>
 struct PsdItems {
-  int bP[NB], bQ[NB], vQ[2 * NB], vI[2 * NB];
-  bool okb[NB], okv[2 * NB];
+  int bP[NB], bQ[NB], vQ[3 * NB], vI[3 * NB];
+  bool okb[NB], okv[3 * NB];
 };
+// blocks per lane for `nthreads` update lanes: the upper triangle of the npairs x npairs block grid; the V items (2 npairs^2 of them)
+// need up to 3 per block slot (npairs^2 * 2 <= 3 * NB * nthreads whenever npairs (npairs + 1) / 2 <= NB * nthreads and npairs >= 3 ...
+// checked by psd_items_fit)
+PSD_HD int psd_blocks_per_lane(int npairs, int nthreads) {
+  int nb = (npairs * (npairs + 1) / 2 + nthreads - 1) / nthreads;
+  while (3 * nb * nthreads < 2 * npairs * npairs) ++nb;
+  return nb;
+}
 template <int NB>
 PSD_HD void psd_items_init(PsdItems<NB> &it, int tid, int nthreads, int npairs, int K2) {
-  const int nblk = npairs * npairs, nv = 2 * nblk; // K2 * npairs == 2 * npairs^2
+  const int ntri = npairs * (npairs + 1) / 2, nv = 2 * npairs * npairs; // K2 * npairs == 2 * npairs^2
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
     const int e = tid + u * nthreads;
-    it.okb[u] = tid < nthreads && e < nblk;
-    const int ec = it.okb[u] ? e : 0;
-    // lanes walk the ROW pairs (consecutive P -> stride ld, odd -> distinct LDS banks); the column pair is uniform across
-    // most of a wave
-    it.bQ[u] = ec / npairs;
-    it.bP[u] = ec % npairs;
+    it.okb[u] = tid < nthreads && e < ntri;
+    // e -> (P, Q), P <= Q, column-major over the upper triangle: Q = the column with Q (Q + 1) / 2 <= e, P = e - Q (Q + 1) / 2
+    // (consecutive lanes walk the ROW pairs of one column pair: distinct rows, stride ld (odd) -> distinct LDS banks)
+    int Q = 0;
+    if (it.okb[u]) {
+      while ((Q + 1) * (Q + 2) / 2 <= e) ++Q;
+    }
+    it.bQ[u] = Q;
+    it.bP[u] = it.okb[u] ? e - Q * (Q + 1) / 2 : 0;
   }
   PSD_UNROLL
-  for (int j = 0; j < 2 * NB; ++j) {
+  for (int j = 0; j < 3 * NB; ++j) {
     const int f = tid + j * nthreads;
     it.okv[j] = tid < nthreads && f < nv;
     const int fc = it.okv[j] ? f : 0;
@@ -92,31 +108,31 @@ PSD_HD void psd_items_init(PsdItems<NB> &it, int tid, int nthreads, int npairs, 
   }
 }
 
-// One update pass, A_dst <- J' A_src J over 2x2 blocks (rows of pair P, columns of pair Q) and V <- V J over (row, pair) items (there
-// are exactly twice as many of those): every lane owns up to NB blocks and 2 NB row pairs and asks for all its tables, then all its
-// operands, before it computes -- the LDS round trips of a lane's items overlap instead of queueing behind each other.  Items beyond
-// the end are clamped to item 0 for the loads and skipped by the stores (no per-item branches in the load phase).  A_dst == A_src
-// is the in-place form of rounds 2-4 (every entry is read and written by the same lane); the pipelined step passes the other copy.
+// where entry (r, c) of the symmetric matrix is stored
+PSD_HD int psd_sym_index(int r, int c, int ld) { return r < c ? r * ld + c : c * ld + r; }
+
+// One update pass, A_dst <- J' A_src J over the 2x2 blocks (rows of pair P, columns of pair Q, P <= Q) and V <- V J over (row, pair)
+// items: every lane owns up to NB blocks and 3 NB row pairs and asks for all its tables, then all its operands, before it computes
+// -- the LDS round trips of a lane's items overlap instead of queueing behind each other.  Items beyond the end are clamped to item
+// 0 for the loads and skipped by the stores (no per-item branches in the load phase).  A_dst == A_src is the in-place form (every
+// entry is read and written by the same lane); the pipelined step passes the other copy.
 template <int NB>
 PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB> &it,
                             int ld, bool rotates = true) {
-  constexpr int NV = 2 * NB;
+  constexpr int NV = 3 * NB;
   int i11[NB], i12[NB], i21[NB], i22[NB];
   RotCS r1[NB], r2[NB];
-  bool own[NB];
+  bool diag[NB];
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
     const PsdPair pq1 = rot_pq[it.bP[u]], pq2 = rot_pq[it.bQ[u]];
     r1[u] = rot_cs[it.bP[u]];
     r2[u] = rot_cs[it.bQ[u]];
-    i11[u] = pq1.x * ld + pq2.x;
-    i12[u] = pq1.x * ld + pq2.y;
-    i21[u] = pq1.y * ld + pq2.x;
-    i22[u] = pq1.y * ld + pq2.y;
-    // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is left otherwise is
-    // rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the convergence threshold and kept
-    // the sweeps going to the cap)
-    own[u] = it.bP[u] == it.bQ[u] && r1[u].s != (real)0;
+    diag[u] = it.bP[u] == it.bQ[u];
+    i11[u] = psd_sym_index(pq1.x, pq2.x, ld);
+    i12[u] = psd_sym_index(pq1.x, pq2.y, ld);
+    i21[u] = psd_sym_index(pq1.y, pq2.x, ld); // diagonal block: the same stored entry as i12 (x < y)
+    i22[u] = psd_sym_index(pq1.y, pq2.y, ld);
   }
   int ip[NV], iq[NV];
   RotCS rq[NV];
@@ -150,9 +166,16 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
       const real r11 = c1 * a11[u] - s1 * a21[u], r12 = c1 * a12[u] - s1 * a22[u];
       const real r21 = s1 * a11[u] + c1 * a21[u], r22 = s1 * a12[u] + c1 * a22[u];
       Adst[i11[u]] = c2 * r11 - s2 * r12;
-      Adst[i12[u]] = own[u] ? (real)0 : s2 * r11 + c2 * r12;
-      Adst[i21[u]] = own[u] ? (real)0 : c2 * r21 - s2 * r22;
       Adst[i22[u]] = s2 * r21 + c2 * r22;
+      if (diag[u]) {
+        // the rotated pair's own off-diagonal entry is zero by construction: store the exact zero (what is left otherwise is
+        // rounding residue of the order eps |a_pp - a_qq|, which for k >~ 100 sits above the convergence threshold and kept
+        // the sweeps going to the cap); a pair that did not rotate keeps its entry (identity)
+        Adst[i12[u]] = s1 != (real)0 ? (real)0 : s2 * r11 + c2 * r12;
+      } else {
+        Adst[i12[u]] = s2 * r11 + c2 * r12;
+        Adst[i21[u]] = c2 * r21 - s2 * r22;
+      }
     }
   }
   PSD_UNROLL
@@ -207,11 +230,15 @@ PSD_HD bool psd_lookahead(const real *A, const PsdPair *rot_pq, const RotCS *rot
   const PsdPair pl = rot_pq[Plo], ph = rot_pq[Phi];
   const RotCS rl = rot_cs[Plo], rh = rot_cs[Phi];
   const int sl = lo == pl.x ? 0 : 1, sh = hi == ph.x ? 0 : 1; // which player of its old pair
-  // the three 2x2 blocks that hold a_lohi, a_lolo, a_hihi: (Plo, Phi), (Plo, Plo), (Phi, Phi) -- twelve independent reads
-  const real b11 = A[pl.x * ld + ph.x], b12 = A[pl.x * ld + ph.y], b21 = A[pl.y * ld + ph.x], b22 = A[pl.y * ld + ph.y];
-  const real l11 = A[pl.x * ld + pl.x], l12 = A[pl.x * ld + pl.y], l21 = A[pl.y * ld + pl.x], l22 = A[pl.y * ld + pl.y];
-  const real h11 = A[ph.x * ld + ph.x], h12 = A[ph.x * ld + ph.y], h21 = A[ph.y * ld + ph.x], h22 = A[ph.y * ld + ph.y];
-  const real apq = psd_block_entry(b11, b12, b21, b22, rl, rh, sl, sh);
+  // the three 2x2 blocks that hold a_lohi, a_lolo, a_hihi: (Plo, Phi), (Plo, Plo), (Phi, Phi) -- ten independent reads
+  // (symmetric storage: entry (r, c) lives at min * ld + max; a pair's own block holds its off-diagonal entry once)
+  const real b11 = A[psd_sym_index(pl.x, ph.x, ld)], b12 = A[psd_sym_index(pl.x, ph.y, ld)];
+  const real b21 = A[psd_sym_index(pl.y, ph.x, ld)], b22 = A[psd_sym_index(pl.y, ph.y, ld)];
+  const real l11 = A[pl.x * ld + pl.x], l12 = A[pl.x * ld + pl.y], l21 = l12, l22 = A[pl.y * ld + pl.y];
+  const real h11 = A[ph.x * ld + ph.x], h12 = A[ph.x * ld + ph.y], h21 = h12, h22 = A[ph.y * ld + ph.y];
+  // the update forms the block with the rows of the pair of SMALLER pair index: the same orientation here, so that the three entries
+  // carry exactly the bits the update stores (the pipelined iteration then equals the two-phase one bit for bit)
+  const real apq = Plo <= Phi ? psd_block_entry(b11, b12, b21, b22, rl, rh, sl, sh) : psd_block_entry(b11, b21, b12, b22, rh, rl, sh, sl);
   const real app = psd_block_entry(l11, l12, l21, l22, rl, rl, sl, sl);
   const real aqq = psd_block_entry(h11, h12, h21, h22, rh, rh, sh, sh);
   pq_out.x = lo;

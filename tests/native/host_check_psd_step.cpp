@@ -27,12 +27,11 @@ void update_all(const real *As, real *Ad, real *V, const PsdPair *pq, const RotC
   }
 }
 void update_dispatch(const real *As, real *Ad, real *V, const PsdPair *pq, const RotCS *cs, int npairs, int K2, int ld, int nt) {
-  switch ((npairs * npairs + nt - 1) / nt) {
+  switch (psd_blocks_per_lane(npairs, nt)) {
   case 1: update_all<1>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
   case 2: update_all<2>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
   case 3: update_all<3>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
-  case 4: update_all<4>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
-  default: update_all<5>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
+  default: update_all<4>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
   }
 }
 } // namespace
