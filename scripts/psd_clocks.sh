@@ -20,6 +20,12 @@ for l in open(sys.argv[1]):
         f = l.split()
         rows.append({f[i]: float(f[i + 1]) for i in range(1, len(f) - 1, 2)})
 cone = [l.strip() for l in open(sys.argv[1]) if l.startswith("cone:")]
+wv = {}
+for l in open(sys.argv[1]):
+    if l.startswith("PSDWAVE"):
+        f = l.split()
+        d = wv.setdefault(f[1], [0.0, 0.0, 0])
+        d[0] += float(f[3]); d[1] += float(f[5]); d[2] += 1
 if not rows:
     print("pipe", sys.argv[2], ": no PSDCLK lines"); sys.exit(0)
 n = len(rows)
@@ -29,6 +35,9 @@ print(f"| SCS_AMD_PSD_PIPE={sys.argv[2]} ({'pipelined step' if sys.argv[2]=='1' 
       f"| unpack+warm {avg['unpack_warm']:.0f} | fro {avg['fro']:.0f} | sweeps {avg['sweeps']:.0f} ({100*avg['sweeps']/tot:.0f} %) | W, WW', pack {avg['tail']:.0f} "
       f"| sweeps per launch {avg['nsweep']:.2f} | steps {avg['steps']:.1f} | rotating steps {avg['rot_steps']:.1f} "
       f"| clocks per rotating step {avg['sweeps']/max(avg['rot_steps'],1):.0f} | {cone[0] if cone else ''} |")
+for name, d in wv.items():
+    if d[2]:
+        print(f"|   {name} wave, per step: work before the barrier {d[0]/d[2]/max(avg['steps'],1):.0f} clocks, waiting at the barrier {d[1]/d[2]/max(avg['steps'],1):.0f} |")
 PY
 done
 cp /tmp/lib_shipped.so scs_amd/lib/libscsamd.so

@@ -409,6 +409,33 @@ __device__ __forceinline__ real psd_unpack_entry(const real *X, int k, bool cplx
 // warm != 0 the iteration starts from A' = Vp' A Vp (nearly diagonal when consecutive ADMM
 // iterates are close) and V = Vp, so it needs 1-2 sweeps instead of ~8; the basis is written back
 // whenever vprev is given.  The host restarts cold every PSD_WARM_RESET calls.
+// lane i <- lane i + 1 (UP) / lane i - 1 (!UP) of a wave, by DPP (v_mov_b32_dpp wave_shl:1 / wave_shr:1): a register move, NOT an LDS
+// instruction (ds_bpermute would queue behind the update waves' LDS traffic, which is what the look-ahead must avoid).  All 64 lanes
+// must be active at the call.  The first / last lane keeps its own value.
+template <bool UP>
+__device__ __forceinline__ int lane_shift1(int v) {
+  return UP ? __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false) : __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+template <bool UP>
+__device__ __forceinline__ PsdRot lane_shift1(const PsdRot &r) {
+  PsdRot o;
+  o.x = lane_shift1<UP>(r.x);
+  o.y = lane_shift1<UP>(r.y);
+  union {
+    real f;
+    int w[sizeof(real) / 4];
+  } a, b;
+  a.f = r.c;
+#pragma unroll
+  for (unsigned j = 0; j < sizeof(real) / 4; ++j) b.w[j] = lane_shift1<UP>(a.w[j]);
+  o.c = b.f;
+  a.f = r.s;
+#pragma unroll
+  for (unsigned j = 0; j < sizeof(real) / 4; ++j) b.w[j] = lane_shift1<UP>(a.w[j]);
+  o.s = b.f;
+  return o;
+}
+
 // PIPE: the pipelined step (round 5) for launches whose largest block leaves room for a second copy of A (order <= PSD_WARM_KMAX);
 // its own instantiation, so that the five-blocks-per-lane update of orders up to 92 does not set this one's register budget
 template <bool PIPE>
@@ -459,6 +486,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   PSD_CLK(clk0);
 #ifdef SCSAMD_PSD_CLOCKS
   int n_steps = 0, n_rot_steps = 0;
+  long long clk_work = 0, clk_wait = 0; // per wave: inside a step before its barrier / waiting at the barrier (pipelined step)
 #endif
   // unpack: full symmetric, diagonal * sqrt(2)  (cones.c:1018-1025)
   for (int e = tid; e < K2 * K2; e += PSD_THREADS) {
@@ -540,10 +568,13 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       constexpr int NB = decltype(nbc)::value;
       PsdItems<NB> items;
       psd_items_init<NB>(items, tid, PSD_PIPE_THREADS, npairs, K2); // the lane's blocks and row pairs: once, not per step
+      if (la) __builtin_amdgcn_s_setprio(3); // the look-ahead wave's chain is the longer one: it issues first on its SIMD
       for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
         if (nothing_to_rotate()) break;
         real offmax = 0;
         int pos_a = lane, pos_b = K2 - 1 - lane; // step 0 (lane = pair index in the look-ahead wave)
+        PsdRot mine{0, 1, (real)1, (real)0};    // look-ahead lane i: pair i of the step being applied, as it wrote it to the tables
+        int la_any = 0;                          // look-ahead wave: does that step rotate at all (its own vote, no LDS read)
         if (la) { // prologue: step 0 from the matrix as it stands
           bool rot = false;
           if (lane < npairs) {
@@ -553,35 +584,52 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
             psd_pair_advance(lane, K2, pos_a, pos_b);
             rot_pq[lane] = pq;
             rot_cs[lane] = cs;
+            mine = PsdRot{pq.x, pq.y, cs.c, cs.s};
           }
-          const int any = __any(rot ? 1 : 0);
-          if (lane == 0) rot_any[0] = any;
+          la_any = __any(rot ? 1 : 0);
+          if (lane == 0) rot_any[0] = la_any;
         }
         __syncthreads();
         for (int step = 0; step < K2 - 1; ++step) {
           const int par = step & 1;
           const int2 *tq = rot_pq + par * PSD_TBL;
           const RotCS *tc = rot_cs + par * PSD_TBL;
-          const bool rotates = rot_any[par] != 0; // uniform
           real *Anext = Acur == A ? A2 : A;
+          bool rotates;
+          PSD_CLK(clk_a);
           if (la) {
+            rotates = la_any != 0;
             if (step + 1 < K2 - 1) {
+              // the records of the pairs that hold this lane's next players: its neighbours' registers (all 64 lanes take part)
+              const PsdRot up = lane_shift1<true>(mine), dn = lane_shift1<false>(mine);
               bool rot = false;
               if (lane < npairs) {
+                const bool edge = lane == 0 || lane == npairs - 1;
+                const PsdRot rec_p = edge ? mine : up, rec_q = lane == 0 ? up : dn;
                 int2 pq;
                 RotCS cs;
-                rot = psd_lookahead(Acur, tq, tc, lane, npairs, pos_a, pos_b, ld, k, thr, offmax, pq, cs);
+                rot = psd_lookahead_rec(Acur, rec_p, rec_q, lane == 0, pos_a, pos_b, ld, k, thr, offmax, pq, cs);
                 psd_pair_advance(lane, K2, pos_a, pos_b);
                 rot_pq[(par ^ 1) * PSD_TBL + lane] = pq;
                 rot_cs[(par ^ 1) * PSD_TBL + lane] = cs;
+                mine = PsdRot{pq.x, pq.y, cs.c, cs.s};
               }
-              const int any = __any(rot ? 1 : 0);
-              if (lane == 0) rot_any[par ^ 1] = any;
+              la_any = __any(rot ? 1 : 0);
+              if (lane == 0) rot_any[par ^ 1] = la_any;
             }
           } else {
+            rotates = rot_any[par] != 0; // uniform
             psd_update_pass<NB>(Acur, Anext, V, tq, tc, items, ld, rotates); // loads first, `rotates` is only needed for the stores
           }
+#ifdef SCSAMD_PSD_CLOCKS
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const long long clk_b = clock64();
+#endif
           __syncthreads();
+#ifdef SCSAMD_PSD_CLOCKS
+          clk_work += clk_b - clk_a;
+          clk_wait += clock64() - clk_b;
+#endif
           PSD_COUNT(n_steps);
           if (rotates) {
             Acur = Anext;
@@ -591,6 +639,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         offmax = block_max(offmax, red);
         if (offmax <= thr) break;
       }
+      if (la) __builtin_amdgcn_s_setprio(0);
     };
     // ---- two-phase step (rounds 2-4): rotation parameters on the first npairs lanes, barrier, in-place update, barrier.  Orders
     // 73..92 (no room for a second copy of A) and K2 = 2.
@@ -726,6 +775,8 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
 #endif
 #ifdef SCSAMD_PSD_CLOCKS
   __syncthreads();
+  if (cone == 0 && (tid & 63) == 0 && (tid == 0 || tid == PSD_THREADS - 64))
+    printf("PSDWAVE %s work %lld wait %lld\n", tid == 0 ? "update" : "lookahead", clk_work, clk_wait);
   if (cone == 0 && tid == 0)
     printf("PSDCLK pipe %d k %d unpack_warm %lld fro %lld sweeps %lld tail %lld nsweep %d steps %d rot_steps %d\n", PIPE ? 1 : 0, k, clk1 - clk0,
            clk2 - clk1, clk3 - clk2, (long long)clock64() - clk3, sweep, n_steps, n_rot_steps);

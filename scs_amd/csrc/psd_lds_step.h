@@ -218,17 +218,26 @@ PSD_HD real psd_block_entry(real a11, real a12, real a21, real a22, const RotCS 
   return cs_ == 0 ? r2.c * ra - r2.s * rb : r2.s * ra + r2.c * rb;
 }
 
-// Look-ahead of lane i (pair i of step s + 1; (p, q) = its players, any order): reads step s's tables and the matrix as it stands
-// BEFORE step s is applied, returns the rotation of its pair for the matrix AFTER step s.  rot_pq rows are sorted (x < y).
-PSD_HD bool psd_lookahead(const real *A, const PsdPair *rot_pq, const RotCS *rot_cs, int i, int npairs, int p, int q, int ld, int k,
-                          real thr, real &offmax, PsdPair &pq_out, RotCS &cs_out) {
-  const int src_p = i == 0 ? 0 : (i == npairs - 1 ? npairs - 1 : i + 1); // pair of step s that holds p
-  const int src_q = i == 0 ? 1 : i - 1;                                    // ... that holds q
+// one pair's record: its players (x < y) and its rotation
+struct PsdRot {
+  int x, y;
+  real c, s;
+};
+
+// Look-ahead of lane i (pair i of step s + 1; (p, q) = its players, any order) from the records of the two pairs of step s that hold p
+// and q: reads the matrix as it stands BEFORE step s is applied, returns the rotation of its pair for the matrix AFTER step s.
+// p_first: the pair holding p has the smaller pair index (only for lane 0).  In the kernel the records come out of the look-ahead
+// wave's OWN registers -- lane i wrote pair i of step s one phase earlier, its neighbours' records arrive by DPP lane shifts -- so the
+// chain of a step holds ONE LDS round trip (the ten matrix entries), issued at the top of the phase before the update waves' traffic
+// (round 5: with the records read back from the LDS tables the look-ahead wave was the critical path, 1 900 of a step's 2 450 clocks,
+// its two dependent round trips queueing behind seven waves' worth of update traffic; profiles/r5_psd_pipelined_step.md).
+PSD_HD bool psd_lookahead_rec(const real *A, const PsdRot &rec_p, const PsdRot &rec_q, bool p_first, int p, int q, int ld, int k, real thr,
+                              real &offmax, PsdPair &pq_out, RotCS &cs_out) {
   const bool swap = p > q;
   const int lo = swap ? q : p, hi = swap ? p : q;
-  const int Plo = swap ? src_q : src_p, Phi = swap ? src_p : src_q;
-  const PsdPair pl = rot_pq[Plo], ph = rot_pq[Phi];
-  const RotCS rl = rot_cs[Plo], rh = rot_cs[Phi];
+  const PsdRot &pl = swap ? rec_q : rec_p, &ph = swap ? rec_p : rec_q; // the pairs of step s that hold lo / hi
+  const bool lo_first = swap ? !p_first : p_first;                      // pair index of lo's pair <= that of hi's pair
+  const RotCS rl{pl.c, pl.s}, rh{ph.c, ph.s};
   const int sl = lo == pl.x ? 0 : 1, sh = hi == ph.x ? 0 : 1; // which player of its old pair
   // the three 2x2 blocks that hold a_lohi, a_lolo, a_hihi: (Plo, Phi), (Plo, Plo), (Phi, Phi) -- ten independent reads
   // (symmetric storage: entry (r, c) lives at min * ld + max; a pair's own block holds its off-diagonal entry once)
@@ -238,13 +247,16 @@ PSD_HD bool psd_lookahead(const real *A, const PsdPair *rot_pq, const RotCS *rot
   const real h11 = A[ph.x * ld + ph.x], h12 = A[ph.x * ld + ph.y], h21 = h12, h22 = A[ph.y * ld + ph.y];
   // the update forms the block with the rows of the pair of SMALLER pair index: the same orientation here, so that the three entries
   // carry exactly the bits the update stores (the pipelined iteration then equals the two-phase one bit for bit)
-  const real apq = Plo <= Phi ? psd_block_entry(b11, b12, b21, b22, rl, rh, sl, sh) : psd_block_entry(b11, b21, b12, b22, rh, rl, sh, sl);
+  const real apq = lo_first ? psd_block_entry(b11, b12, b21, b22, rl, rh, sl, sh) : psd_block_entry(b11, b21, b12, b22, rh, rl, sh, sl);
   const real app = psd_block_entry(l11, l12, l21, l22, rl, rl, sl, sl);
   const real aqq = psd_block_entry(h11, h12, h21, h22, rh, rh, sh, sh);
   pq_out.x = lo;
   pq_out.y = hi;
   return psd_make_rotation(apq, app, aqq, hi, k, thr, offmax, cs_out);
 }
+// which pairs of step s hold the players of pair i of step s + 1 (circle method, see the header)
+PSD_HD int psd_source_of_p(int i, int npairs) { return i == 0 ? 0 : (i == npairs - 1 ? npairs - 1 : i + 1); }
+PSD_HD int psd_source_of_q(int i) { return i == 0 ? 1 : i - 1; }
 
 // first step of a sweep: nothing is pending, the three entries are read as they stand
 PSD_HD bool psd_first_rotation(const real *A, int p, int q, int ld, int k, real thr, real &offmax, PsdPair &pq_out, RotCS &cs_out) {

@@ -85,9 +85,11 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
       }
     } else {
       bool any = false;
+      std::vector<PsdRot> mine(npairs), prev(npairs); // the look-ahead lanes' own registers: pair i of the current step
       for (int i = 0; i < npairs; ++i) { // prologue: step 0 from the matrix as it stands
         any |= psd_first_rotation(Acur, pa[i], pb[i], ld, k, thr, offmax, tq[i], tc[i]);
         psd_pair_advance(i, K2, pa[i], pb[i]);
+        mine[i] = PsdRot{tq[i].x, tq[i].y, tc[i].c, tc[i].s};
       }
       rot_any[0] = any;
       for (int step = 0; step < K2 - 1; ++step, ++steps) {
@@ -95,7 +97,8 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
         const PsdPair *q0 = tq.data() + par * TBL;
         const RotCS *c0 = tc.data() + par * TBL;
         const bool rotates = rot_any[par] != 0;
-        // look-ahead wave (reads Acur and step `step`'s tables only; writes the other tables)
+        // look-ahead wave (reads Acur and its own registers' records of step `step`; writes the other tables)
+        prev = mine;
         if (step + 1 < K2 - 1) {
           bool nany = false;
           for (int i = 0; i < npairs; ++i) {
@@ -104,10 +107,15 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
             if (!((q0[sp].x == pa[i] || q0[sp].y == pa[i]) && (q0[sq].x == pb[i] || q0[sq].y == pb[i]))) ++mism;
             PsdPair pq;
             RotCS cs;
-            nany |= psd_lookahead(Acur, q0, c0, i, npairs, pa[i], pb[i], ld, k, thr, offmax, pq, cs);
+            // the kernel: lane i + 1's record by a DPP shift up, lane i - 1's by a shift down (lane 0 and the last lane use their own)
+            const PsdRot &up = prev[i + 1 < npairs ? i + 1 : i], &dn = prev[i > 0 ? i - 1 : i];
+            const PsdRot &rec_p = (i == 0 || i == npairs - 1) ? prev[i] : up, &rec_q = i == 0 ? up : dn;
+            if (&rec_p != &prev[sp] || &rec_q != &prev[sq]) ++mism;
+            nany |= psd_lookahead_rec(Acur, rec_p, rec_q, i == 0, pa[i], pb[i], ld, k, thr, offmax, pq, cs);
             psd_pair_advance(i, K2, pa[i], pb[i]);
             tq[(par ^ 1) * TBL + i] = pq;
             tc[(par ^ 1) * TBL + i] = cs;
+            mine[i] = PsdRot{pq.x, pq.y, cs.c, cs.s};
           }
           rot_any[par ^ 1] = nany;
         }
