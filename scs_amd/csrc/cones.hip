@@ -433,6 +433,10 @@ __device__ __forceinline__ PsdRot lane_shift1(const PsdRot &r) {
 #pragma unroll
   for (unsigned j = 0; j < sizeof(real) / 4; ++j) b.w[j] = lane_shift1<UP>(a.w[j]);
   o.s = b.f;
+  a.f = r.t;
+#pragma unroll
+  for (unsigned j = 0; j < sizeof(real) / 4; ++j) b.w[j] = lane_shift1<UP>(a.w[j]);
+  o.t = b.f;
   return o;
 }
 
@@ -573,18 +577,15 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         if (nothing_to_rotate()) break;
         real offmax = 0;
         int pos_a = lane, pos_b = K2 - 1 - lane; // step 0 (lane = pair index in the look-ahead wave)
-        PsdRot mine{0, 1, (real)1, (real)0};    // look-ahead lane i: pair i of the step being applied, as it wrote it to the tables
+        PsdRot mine{0, 1, (real)1, (real)0, (real)0}; // look-ahead lane i: pair i of the step being applied, as it wrote it to the tables
         int la_any = 0;                          // look-ahead wave: does that step rotate at all (its own vote, no LDS read)
         if (la) { // prologue: step 0 from the matrix as it stands
           bool rot = false;
           if (lane < npairs) {
-            int2 pq;
-            RotCS cs;
-            rot = psd_first_rotation(Acur, pos_a, pos_b, ld, k, thr, offmax, pq, cs);
+            rot = psd_first_rotation(Acur, pos_a, pos_b, ld, k, thr, offmax, mine);
             psd_pair_advance(lane, K2, pos_a, pos_b);
-            rot_pq[lane] = pq;
-            rot_cs[lane] = cs;
-            mine = PsdRot{pq.x, pq.y, cs.c, cs.s};
+            rot_pq[lane] = make_int2(mine.x, mine.y);
+            rot_cs[lane] = RotCS{mine.c, mine.s};
           }
           la_any = __any(rot ? 1 : 0);
           if (lane == 0) rot_any[0] = la_any;
@@ -606,13 +607,10 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
               if (lane < npairs) {
                 const bool edge = lane == 0 || lane == npairs - 1;
                 const PsdRot rec_p = edge ? mine : up, rec_q = lane == 0 ? up : dn;
-                int2 pq;
-                RotCS cs;
-                rot = psd_lookahead_rec(Acur, rec_p, rec_q, lane == 0, pos_a, pos_b, ld, k, thr, offmax, pq, cs);
+                rot = psd_lookahead_rec(Acur, rec_p, rec_q, pos_a, pos_b, ld, k, thr, offmax, mine);
                 psd_pair_advance(lane, K2, pos_a, pos_b);
-                rot_pq[(par ^ 1) * PSD_TBL + lane] = pq;
-                rot_cs[(par ^ 1) * PSD_TBL + lane] = cs;
-                mine = PsdRot{pq.x, pq.y, cs.c, cs.s};
+                rot_pq[(par ^ 1) * PSD_TBL + lane] = make_int2(mine.x, mine.y);
+                rot_cs[(par ^ 1) * PSD_TBL + lane] = RotCS{mine.c, mine.s};
               }
               la_any = __any(rot ? 1 : 0);
               if (lane == 0) rot_any[par ^ 1] = la_any;
@@ -656,13 +654,12 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         for (int step = 0; step < K2 - 1; ++step) {
           const int par = step & 1;
           if (tid < npairs) {
-            int2 pq;
-            RotCS cs;
+            PsdRot r;
             // an off-diagonal entry at or below the threshold is left alone (identity); t = sgn(d) b / (|d| + sqrt(d^2 + b^2))
-            if (psd_first_rotation(A, pos_a, pos_b, ld, k, thr, offmax, pq, cs)) rot_any[par] = 1;
+            if (psd_first_rotation(A, pos_a, pos_b, ld, k, thr, offmax, r)) rot_any[par] = 1;
             psd_pair_advance(tid, K2, pos_a, pos_b);
-            rot_pq[tid] = pq;
-            rot_cs[tid] = cs;
+            rot_pq[tid] = make_int2(r.x, r.y);
+            rot_cs[tid] = RotCS{r.c, r.s};
             if (tid == 0) rot_any[par ^ 1] = 0; // nobody reads the other parity before the next step's barrier
           }
           __syncthreads();

@@ -13,7 +13,7 @@
 //     look-ahead lanes (their own wave) read A[cur], tables[s & 1]; apply step s's rotations to just the three entries
 //                     a_pq, a_pp, a_qq their pair of step s+1 needs; write tables[(s+1) & 1], rot_any[(s+1) & 1]
 //   barrier;  cur ^= rot_any[s & 1]
-// Circle method: pair i of step s+1 takes its first player from pair i+1 of step s (pair 0 keeps player 0; the last pair takes
+// (Pairs are kept in position order (x, y), not sorted.)  Circle method: pair i of step s+1 takes its first player from pair i+1 of step s (pair 0 keeps player 0; the last pair takes
 // the OTHER player of itself) and its second player from pair i-1 (pair 0: from pair 1) -- so the look-ahead lane knows which two
 // table rows to read without an inverse table.
 #pragma once
@@ -44,21 +44,26 @@ PSD_HD real psd_abs(real x) { return x < 0 ? -x : x; }
 // -- two reciprocal square roots instead of a square root, a division and a reciprocal square root in sequence: on this part each of
 // them is a Newton sequence, and the chain sits on the critical path of every Jacobi step.  c^2 + s^2 = 1 holds to
 // rounding as before.  Outside the range where d^2 + b^2 is a normal number the sequential form is kept.
-PSD_HD void jacobi_cs(real d, real b, real &c, real &s) {
+PSD_HD void jacobi_cs(real d, real b, real &c, real &s, real &t) { // t = s / c = tan of the rotation angle
   const real g = d * d + b * b;
   const real lo = sizeof(real) == 8 ? (real)1e-290 : (real)1e-30, hi = sizeof(real) == 8 ? (real)1e290 : (real)1e30;
   if (g > lo && g < hi) {
     const real q = rsqrt(g);
     const real u = (real)0.5 + (real)0.5 * psd_abs(d) * q;
-    const real rc = rsqrt(u);
+    const real rc = rsqrt(u); // = 1 / c
     c = u * rc;
     s = (d >= 0 ? b : -b) * ((real)0.5 * q * rc);
+    t = s * rc;
   } else {
     const real h = sqrt(g);
-    const real t = (d >= 0 ? b : -b) / (psd_abs(d) + h);
+    t = (d >= 0 ? b : -b) / (psd_abs(d) + h);
     c = rsqrt(t * t + (real)1);
     s = t * c;
   }
+}
+PSD_HD void jacobi_cs(real d, real b, real &c, real &s) {
+  real t;
+  jacobi_cs(d, b, c, s, t);
 }
 
 // The (block, row-pair) items of a lane: which 2x2 blocks (rows of pair P, columns of pair Q, P <= Q) and which (row i, pair Q) items of V
@@ -194,82 +199,70 @@ PSD_HD void psd_pair_advance(int i, int K2, int &pos_a, int &pos_b) {
   pos_b = pos_b == K2 - 1 ? 1 : pos_b + 1;
 }
 
-// rotation of the pair (lo, hi), lo < hi, from its three entries; entries at or below the threshold -- and the padding index of an
-// odd order -- are left alone (identity).  Returns whether it rotates; tracks the sweep's largest off-diagonal entry.
-PSD_HD bool psd_make_rotation(real apq, real app, real aqq, int hi, int k, real thr, real &offmax, RotCS &cs) {
-  real c = 1, s = 0;
+// one pair's record as the look-ahead lanes keep it in registers: its players (x, y) in position order -- NOT sorted: the rotation
+// is formed for the order (x, y) and applied in that order, any order describes the same plane rotation -- its rotation and
+// t = s / c
+struct PsdRot {
+  int x, y;
+  real c, s, t;
+};
+
+// rotation of the pair (p, q) from its three entries (a_pq, a_pp, a_qq); entries at or below the threshold -- and the padding index of
+// an odd order -- are left alone (identity).  Returns whether it rotates; tracks the sweep's largest off-diagonal entry.
+PSD_HD bool psd_make_rotation(real apq, real app, real aqq, int p, int q, int k, real thr, real &offmax, PsdRot &r) {
+  real c = 1, s = 0, t = 0;
   const real aa = psd_abs(apq);
   bool rot = false;
-  if (hi < k) {
+  if ((p > q ? p : q) < k) {
     offmax = aa > offmax ? aa : offmax;
     if (aa > thr) {
-      jacobi_cs(aqq - app, (real)2 * apq, c, s);
+      jacobi_cs(aqq - app, (real)2 * apq, c, s, t);
       rot = true;
     }
   }
-  cs = RotCS{c, s};
+  r = PsdRot{p, q, c, s, t};
   return rot;
 }
 
-// one entry (row side rs, column side cs_) of the 2x2 block J1' [a11 a12; a21 a22] J2 -- the expressions of psd_update_pass
-PSD_HD real psd_block_entry(real a11, real a12, real a21, real a22, const RotCS &r1, const RotCS &r2, int rs, int cs_) {
-  const real ra = rs == 0 ? r1.c * a11 - r1.s * a21 : r1.s * a11 + r1.c * a21; // row rs of J1' A, column 0
-  const real rb = rs == 0 ? r1.c * a12 - r1.s * a22 : r1.s * a12 + r1.c * a22; // column 1
-  return cs_ == 0 ? r2.c * ra - r2.s * rb : r2.s * ra + r2.c * rb;
-}
-
-// one pair's record: its players (x < y) and its rotation
-struct PsdRot {
-  int x, y;
-  real c, s;
-};
-
-// Look-ahead of lane i (pair i of step s + 1; (p, q) = its players, any order) from the records of the two pairs of step s that hold p
-// and q: reads the matrix as it stands BEFORE step s is applied, returns the rotation of its pair for the matrix AFTER step s.
-// p_first: the pair holding p has the smaller pair index (only for lane 0).  In the kernel the records come out of the look-ahead
-// wave's OWN registers -- lane i wrote pair i of step s one phase earlier, its neighbours' records arrive by DPP lane shifts -- so the
-// chain of a step holds ONE LDS round trip (the ten matrix entries), issued at the top of the phase before the update waves' traffic
-// (round 5: with the records read back from the LDS tables the look-ahead wave was the critical path, 1 900 of a step's 2 450 clocks,
-// its two dependent round trips queueing behind seven waves' worth of update traffic; profiles/r5_psd_pipelined_step.md).
-PSD_HD bool psd_lookahead_rec(const real *A, const PsdRot &rec_p, const PsdRot &rec_q, bool p_first, int p, int q, int ld, int k, real thr,
-                              real &offmax, PsdPair &pq_out, RotCS &cs_out) {
-  const bool swap = p > q;
-  const int lo = swap ? q : p, hi = swap ? p : q;
-  const PsdRot &pl = swap ? rec_q : rec_p, &ph = swap ? rec_p : rec_q; // the pairs of step s that hold lo / hi
-  const bool lo_first = swap ? !p_first : p_first;                      // pair index of lo's pair <= that of hi's pair
-  const RotCS rl{pl.c, pl.s}, rh{ph.c, ph.s};
-  const int sl = lo == pl.x ? 0 : 1, sh = hi == ph.x ? 0 : 1; // which player of its old pair
-  // the three 2x2 blocks that hold a_lohi, a_lolo, a_hihi: (Plo, Phi), (Plo, Plo), (Phi, Phi) -- ten independent reads
-  // (symmetric storage: entry (r, c) lives at min * ld + max; a pair's own block holds its off-diagonal entry once)
-  const real b11 = A[psd_sym_index(pl.x, ph.x, ld)], b12 = A[psd_sym_index(pl.x, ph.y, ld)];
-  const real b21 = A[psd_sym_index(pl.y, ph.x, ld)], b22 = A[psd_sym_index(pl.y, ph.y, ld)];
-  const real l11 = A[pl.x * ld + pl.x], l12 = A[pl.x * ld + pl.y], l21 = l12, l22 = A[pl.y * ld + pl.y];
-  const real h11 = A[ph.x * ld + ph.x], h12 = A[ph.x * ld + ph.y], h21 = h12, h22 = A[ph.y * ld + ph.y];
-  // the update forms the block with the rows of the pair of SMALLER pair index: the same orientation here, so that the three entries
-  // carry exactly the bits the update stores (the pipelined iteration then equals the two-phase one bit for bit)
-  const real apq = lo_first ? psd_block_entry(b11, b12, b21, b22, rl, rh, sl, sh) : psd_block_entry(b11, b21, b12, b22, rh, rl, sh, sl);
-  const real app = psd_block_entry(l11, l12, l21, l22, rl, rl, sl, sl);
-  const real aqq = psd_block_entry(h11, h12, h21, h22, rh, rh, sh, sh);
-  pq_out.x = lo;
-  pq_out.y = hi;
-  return psd_make_rotation(apq, app, aqq, hi, k, thr, offmax, cs_out);
+// Look-ahead of lane i (pair i of step s + 1, players p and q) from the records of the two pairs of step s that hold p and q: reads
+// the matrix as it stands BEFORE step s is applied, returns the rotation of (p, q) for the matrix AFTER step s.  In the kernel the
+// records come out of the look-ahead wave's OWN registers -- lane i formed pair i of step s one phase earlier, its neighbours' records
+// arrive by DPP lane shifts -- so the chain of a step holds ONE LDS round trip (eight matrix entries).
+//   a'_pq = (column sp of J_P)' B (column sq of J_Q),  B = A[pair P, pair Q]                       -- six multiply-adds
+//   a'_pp = a_pp -/+ t_P a_xy(P)   (p is the first / second player of P; the rotation annihilates a_xy: the classical update)
+// (Round 5, measured: the look-ahead wave is bound by INSTRUCTION ISSUE -- one wave, 4 clocks per instruction -- not by LDS latency: the
+// first form, which restated the update's two-level block product for all three entries and sorted the pair, took 1 900 clocks of a
+// 2 450-clock step in ~430 instructions; profiles/r5_psd_pipelined_step.md.  The diagonal entries therefore differ from what the update
+// stores by rounding, O(eps |a|): the rotation angle moves by that much, nothing else.)
+PSD_HD bool psd_lookahead_rec(const real *A, const PsdRot &P, const PsdRot &Q, int p, int q, int ld, int k, real thr, real &offmax,
+                              PsdRot &out) {
+  const bool sp = p != P.x, sq = q != Q.x; // p / q is the second player of its old pair
+  const real b11 = A[psd_sym_index(P.x, Q.x, ld)], b12 = A[psd_sym_index(P.x, Q.y, ld)];
+  const real b21 = A[psd_sym_index(P.y, Q.x, ld)], b22 = A[psd_sym_index(P.y, Q.y, ld)];
+  const real app0 = A[p * ld + p], aqq0 = A[q * ld + q];
+  const real pxy = A[psd_sym_index(P.x, P.y, ld)], qxy = A[psd_sym_index(Q.x, Q.y, ld)];
+  // column sp of J_P = [c -s; s c]' ... row-rotation coefficients of the update: side 0: (c, -s), side 1: (s, c)
+  const real u0 = sp ? P.s : P.c, u1 = sp ? P.c : -P.s;
+  const real v0 = sq ? Q.s : Q.c, v1 = sq ? Q.c : -Q.s;
+  const real ra = u0 * b11 + u1 * b21, rb = u0 * b12 + u1 * b22;
+  const real apq = v0 * ra + v1 * rb;
+  const real app = app0 + (sp ? P.t : -P.t) * pxy;
+  const real aqq = aqq0 + (sq ? Q.t : -Q.t) * qxy;
+  return psd_make_rotation(apq, app, aqq, p, q, k, thr, offmax, out);
 }
 // which pairs of step s hold the players of pair i of step s + 1 (circle method, see the header)
 PSD_HD int psd_source_of_p(int i, int npairs) { return i == 0 ? 0 : (i == npairs - 1 ? npairs - 1 : i + 1); }
 PSD_HD int psd_source_of_q(int i) { return i == 0 ? 1 : i - 1; }
 
-// first step of a sweep: nothing is pending, the three entries are read as they stand
-PSD_HD bool psd_first_rotation(const real *A, int p, int q, int ld, int k, real thr, real &offmax, PsdPair &pq_out, RotCS &cs_out) {
-  const int lo = p > q ? q : p, hi = p > q ? p : q;
-  pq_out.x = lo;
-  pq_out.y = hi;
-  const real apq = A[lo * ld + hi];
+// first step of a sweep (and every step of the two-phase form): nothing is pending, the three entries are read as they stand
+PSD_HD bool psd_first_rotation(const real *A, int p, int q, int ld, int k, real thr, real &offmax, PsdRot &out) {
+  const real apq = A[psd_sym_index(p, q, ld)];
   real app = 0, aqq = 0;
-  if (hi < k && psd_abs(apq) > thr) {
-    app = A[lo * ld + lo];
-    aqq = A[hi * ld + hi];
+  if ((p > q ? p : q) < k && psd_abs(apq) > thr) {
+    app = A[p * ld + p];
+    aqq = A[q * ld + q];
   }
-  return psd_make_rotation(apq, app, aqq, hi, k, thr, offmax, cs_out);
+  return psd_make_rotation(apq, app, aqq, p, q, k, thr, offmax, out);
 }
 
 } // namespace scsamd

@@ -76,8 +76,11 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
       for (int step = 0; step < K2 - 1; ++step, ++steps) {
         bool any = false;
         for (int i = 0; i < npairs; ++i) { // phase 1
-          any |= psd_first_rotation(Acur, pa[i], pb[i], ld, k, thr, offmax, tq[i], tc[i]);
+          PsdRot r;
+          any |= psd_first_rotation(Acur, pa[i], pb[i], ld, k, thr, offmax, r);
           psd_pair_advance(i, K2, pa[i], pb[i]);
+          tq[i] = PsdPair{r.x, r.y};
+          tc[i] = RotCS{r.c, r.s};
         }
         if (!any) continue; // barrier; uniform skip
         ++rsteps;
@@ -87,9 +90,10 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
       bool any = false;
       std::vector<PsdRot> mine(npairs), prev(npairs); // the look-ahead lanes' own registers: pair i of the current step
       for (int i = 0; i < npairs; ++i) { // prologue: step 0 from the matrix as it stands
-        any |= psd_first_rotation(Acur, pa[i], pb[i], ld, k, thr, offmax, tq[i], tc[i]);
+        any |= psd_first_rotation(Acur, pa[i], pb[i], ld, k, thr, offmax, mine[i]);
         psd_pair_advance(i, K2, pa[i], pb[i]);
-        mine[i] = PsdRot{tq[i].x, tq[i].y, tc[i].c, tc[i].s};
+        tq[i] = PsdPair{mine[i].x, mine[i].y};
+        tc[i] = RotCS{mine[i].c, mine[i].s};
       }
       rot_any[0] = any;
       for (int step = 0; step < K2 - 1; ++step, ++steps) {
@@ -105,17 +109,14 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
             // the rule under test: the players of pair i of the next step sit in the pairs psd_lookahead reads
             const int sp = i == 0 ? 0 : (i == npairs - 1 ? npairs - 1 : i + 1), sq = i == 0 ? 1 : i - 1;
             if (!((q0[sp].x == pa[i] || q0[sp].y == pa[i]) && (q0[sq].x == pb[i] || q0[sq].y == pb[i]))) ++mism;
-            PsdPair pq;
-            RotCS cs;
             // the kernel: lane i + 1's record by a DPP shift up, lane i - 1's by a shift down (lane 0 and the last lane use their own)
             const PsdRot &up = prev[i + 1 < npairs ? i + 1 : i], &dn = prev[i > 0 ? i - 1 : i];
             const PsdRot &rec_p = (i == 0 || i == npairs - 1) ? prev[i] : up, &rec_q = i == 0 ? up : dn;
             if (&rec_p != &prev[sp] || &rec_q != &prev[sq]) ++mism;
-            nany |= psd_lookahead_rec(Acur, rec_p, rec_q, i == 0, pa[i], pb[i], ld, k, thr, offmax, pq, cs);
+            nany |= psd_lookahead_rec(Acur, rec_p, rec_q, pa[i], pb[i], ld, k, thr, offmax, mine[i]);
             psd_pair_advance(i, K2, pa[i], pb[i]);
-            tq[(par ^ 1) * TBL + i] = pq;
-            tc[(par ^ 1) * TBL + i] = cs;
-            mine[i] = PsdRot{pq.x, pq.y, cs.c, cs.s};
+            tq[(par ^ 1) * TBL + i] = PsdPair{mine[i].x, mine[i].y};
+            tc[(par ^ 1) * TBL + i] = RotCS{mine[i].c, mine[i].s};
           }
           rot_any[par ^ 1] = nany;
         }
