@@ -578,7 +578,18 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         real offmax = 0;
         int pos_a = lane, pos_b = K2 - 1 - lane; // step 0 (lane = pair index in the look-ahead wave)
         PsdRot mine{0, 1, (real)1, (real)0, (real)0}; // look-ahead lane i: pair i of the step being applied, as it wrote it to the tables
-        int la_any = 0;                          // look-ahead wave: does that step rotate at all (its own vote, no LDS read)
+        PsdLaPlan plan;                                // ... and what it will read / multiply for its pair of the NEXT step (psd_la_prepare)
+        int la_any = 0;                                // look-ahead wave: does that step rotate at all (its own vote, no LDS read)
+        // the records of the pairs that hold this lane's next players are its neighbours' registers (DPP; all 64 lanes take part);
+        // formed right after `mine`, i.e. BEFORE the barrier that opens the phase in which the plan's reads are issued
+        auto la_prepare = [&]() {
+          const PsdRot up = lane_shift1<true>(mine), dn = lane_shift1<false>(mine);
+          if (lane < npairs) {
+            const bool edge = lane == 0 || lane == npairs - 1;
+            const PsdRot rec_p = edge ? mine : up, rec_q = lane == 0 ? up : dn;
+            psd_la_prepare(plan, rec_p, rec_q, pos_a, pos_b, ld);
+          }
+        };
         if (la) { // prologue: step 0 from the matrix as it stands
           bool rot = false;
           if (lane < npairs) {
@@ -589,6 +600,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
           }
           la_any = __any(rot ? 1 : 0);
           if (lane == 0) rot_any[0] = la_any;
+          if (K2 - 1 > 1) la_prepare();
         }
         __syncthreads();
         for (int step = 0; step < K2 - 1; ++step) {
@@ -601,19 +613,16 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
           if (la) {
             rotates = la_any != 0;
             if (step + 1 < K2 - 1) {
-              // the records of the pairs that hold this lane's next players: its neighbours' registers (all 64 lanes take part)
-              const PsdRot up = lane_shift1<true>(mine), dn = lane_shift1<false>(mine);
               bool rot = false;
               if (lane < npairs) {
-                const bool edge = lane == 0 || lane == npairs - 1;
-                const PsdRot rec_p = edge ? mine : up, rec_q = lane == 0 ? up : dn;
-                rot = psd_lookahead_rec(Acur, rec_p, rec_q, pos_a, pos_b, ld, k, thr, offmax, mine);
+                rot = psd_la_finish(Acur, plan, k, thr, offmax, mine); // its eight reads open the phase's LDS queue
                 psd_pair_advance(lane, K2, pos_a, pos_b);
                 rot_pq[(par ^ 1) * PSD_TBL + lane] = make_int2(mine.x, mine.y);
                 rot_cs[(par ^ 1) * PSD_TBL + lane] = RotCS{mine.c, mine.s};
               }
               la_any = __any(rot ? 1 : 0);
               if (lane == 0) rot_any[par ^ 1] = la_any;
+              if (step + 2 < K2 - 1) la_prepare(); // for the phase after the barrier
             }
           } else {
             rotates = rot_any[par] != 0; // uniform

@@ -76,20 +76,21 @@ PSD_HD void jacobi_cs(real d, real b, real &c, real &s) {
 // The lower triangle is never read after the warm start.
 template <int NB>
 struct PsdItems {
-  int bP[NB], bQ[NB], vQ[3 * NB], vI[3 * NB];
+  int bP[NB], bQ[NB], vQ, vI[3 * NB];
   bool okb[NB], okv[3 * NB];
 };
-// blocks per lane for `nthreads` update lanes: the upper triangle of the npairs x npairs block grid; the V items (2 npairs^2 of them)
-// need up to 3 per block slot (npairs^2 * 2 <= 3 * NB * nthreads whenever npairs (npairs + 1) / 2 <= NB * nthreads and npairs >= 3 ...
-// checked by psd_items_fit)
+// blocks per lane for `nthreads` update lanes: the upper triangle of the npairs x npairs block grid, NB blocks per lane; the (row,
+// pair) items of V: a lane takes up to 3 NB consecutive rows of ONE pair Q (one table read serves them all), so npairs *
+// ceil(K2 / (3 NB)) lanes must exist
+PSD_HD int psd_v_groups(int K2, int nb) { return (K2 + 3 * nb - 1) / (3 * nb); }
 PSD_HD int psd_blocks_per_lane(int npairs, int nthreads) {
   int nb = (npairs * (npairs + 1) / 2 + nthreads - 1) / nthreads;
-  while (3 * nb * nthreads < 2 * npairs * npairs) ++nb;
+  while (npairs * psd_v_groups(2 * npairs, nb) > nthreads) ++nb;
   return nb;
 }
 template <int NB>
 PSD_HD void psd_items_init(PsdItems<NB> &it, int tid, int nthreads, int npairs, int K2) {
-  const int ntri = npairs * (npairs + 1) / 2, nv = 2 * npairs * npairs; // K2 * npairs == 2 * npairs^2
+  const int ntri = npairs * (npairs + 1) / 2;
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
     const int e = tid + u * nthreads;
@@ -103,13 +104,15 @@ PSD_HD void psd_items_init(PsdItems<NB> &it, int tid, int nthreads, int npairs, 
     it.bQ[u] = Q;
     it.bP[u] = it.okb[u] ? e - Q * (Q + 1) / 2 : 0;
   }
+  const int G = psd_v_groups(K2, NB); // lanes per pair Q
+  const bool lane_ok = tid < nthreads && tid < npairs * G;
+  const int tq = lane_ok ? tid : 0;
+  it.vQ = tq / G;
+  const int i0 = (tq % G) * 3 * NB;
   PSD_UNROLL
   for (int j = 0; j < 3 * NB; ++j) {
-    const int f = tid + j * nthreads;
-    it.okv[j] = tid < nthreads && f < nv;
-    const int fc = it.okv[j] ? f : 0;
-    it.vQ[j] = fc / K2;
-    it.vI[j] = fc % K2; // consecutive rows: stride ld
+    it.okv[j] = lane_ok && i0 + j < K2;
+    it.vI[j] = it.okv[j] ? i0 + j : 0; // consecutive lanes: rows 3 NB apart, stride 3 NB ld
   }
 }
 
@@ -140,13 +143,12 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
     i22[u] = psd_sym_index(pq1.y, pq2.y, ld);
   }
   int ip[NV], iq[NV];
-  RotCS rq[NV];
+  const PsdPair pqv = rot_pq[it.vQ];
+  const RotCS rq = rot_cs[it.vQ];
   PSD_UNROLL
   for (int j = 0; j < NV; ++j) {
-    const PsdPair pq2 = rot_pq[it.vQ[j]];
-    rq[j] = rot_cs[it.vQ[j]];
-    ip[j] = it.vI[j] * ld + pq2.x;
-    iq[j] = it.vI[j] * ld + pq2.y;
+    ip[j] = it.vI[j] * ld + pqv.x;
+    iq[j] = it.vI[j] * ld + pqv.y;
   }
   real a11[NB], a12[NB], a21[NB], a22[NB], vp[NV], vq[NV];
   PSD_UNROLL
@@ -186,8 +188,8 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
   PSD_UNROLL
   for (int j = 0; j < NV; ++j) {
     if (it.okv[j]) {
-      V[ip[j]] = rq[j].c * vp[j] - rq[j].s * vq[j];
-      V[iq[j]] = rq[j].s * vp[j] + rq[j].c * vq[j];
+      V[ip[j]] = rq.c * vp[j] - rq.s * vq[j];
+      V[iq[j]] = rq.s * vp[j] + rq.c * vq[j];
     }
   }
 }
@@ -234,21 +236,48 @@ PSD_HD bool psd_make_rotation(real apq, real app, real aqq, int p, int q, int k,
 // first form, which restated the update's two-level block product for all three entries and sorted the pair, took 1 900 clocks of a
 // 2 450-clock step in ~430 instructions; profiles/r5_psd_pipelined_step.md.  The diagonal entries therefore differ from what the update
 // stores by rounding, O(eps |a|): the rotation angle moves by that much, nothing else.)
+// The look-ahead in two parts: PREPARE (no matrix entry needed: which eight entries, which coefficients -- runs at the END of the previous
+// phase, so that the eight reads are the very first LDS requests of the next phase, ahead of the update waves' traffic in the CU's LDS
+// queue) and FINISH (the reads, sixteen multiply-adds, the rotation).
+struct PsdLaPlan {
+  int a[8];                 // b11, b12, b21, b22, a_pp, a_qq, a_xy(P), a_xy(Q)
+  real u0, u1, v0, v1, tp, tq;
+  int p, q;
+};
+PSD_HD void psd_la_prepare(PsdLaPlan &pl, const PsdRot &P, const PsdRot &Q, int p, int q, int ld) {
+  const bool sp = p != P.x, sq = q != Q.x; // p / q is the second player of its old pair
+  pl.a[0] = psd_sym_index(P.x, Q.x, ld);
+  pl.a[1] = psd_sym_index(P.x, Q.y, ld);
+  pl.a[2] = psd_sym_index(P.y, Q.x, ld);
+  pl.a[3] = psd_sym_index(P.y, Q.y, ld);
+  pl.a[4] = p * ld + p;
+  pl.a[5] = q * ld + q;
+  pl.a[6] = psd_sym_index(P.x, P.y, ld);
+  pl.a[7] = psd_sym_index(Q.x, Q.y, ld);
+  // row-rotation coefficients of the update: first player (c, -s), second player (s, c)
+  pl.u0 = sp ? P.s : P.c;
+  pl.u1 = sp ? P.c : -P.s;
+  pl.v0 = sq ? Q.s : Q.c;
+  pl.v1 = sq ? Q.c : -Q.s;
+  pl.tp = sp ? P.t : -P.t;
+  pl.tq = sq ? Q.t : -Q.t;
+  pl.p = p;
+  pl.q = q;
+}
+PSD_HD bool psd_la_finish(const real *A, const PsdLaPlan &pl, int k, real thr, real &offmax, PsdRot &out) {
+  const real b11 = A[pl.a[0]], b12 = A[pl.a[1]], b21 = A[pl.a[2]], b22 = A[pl.a[3]];
+  const real app0 = A[pl.a[4]], aqq0 = A[pl.a[5]], pxy = A[pl.a[6]], qxy = A[pl.a[7]];
+  const real ra = pl.u0 * b11 + pl.u1 * b21, rb = pl.u0 * b12 + pl.u1 * b22;
+  const real apq = pl.v0 * ra + pl.v1 * rb;
+  const real app = app0 + pl.tp * pxy;
+  const real aqq = aqq0 + pl.tq * qxy;
+  return psd_make_rotation(apq, app, aqq, pl.p, pl.q, k, thr, offmax, out);
+}
 PSD_HD bool psd_lookahead_rec(const real *A, const PsdRot &P, const PsdRot &Q, int p, int q, int ld, int k, real thr, real &offmax,
                               PsdRot &out) {
-  const bool sp = p != P.x, sq = q != Q.x; // p / q is the second player of its old pair
-  const real b11 = A[psd_sym_index(P.x, Q.x, ld)], b12 = A[psd_sym_index(P.x, Q.y, ld)];
-  const real b21 = A[psd_sym_index(P.y, Q.x, ld)], b22 = A[psd_sym_index(P.y, Q.y, ld)];
-  const real app0 = A[p * ld + p], aqq0 = A[q * ld + q];
-  const real pxy = A[psd_sym_index(P.x, P.y, ld)], qxy = A[psd_sym_index(Q.x, Q.y, ld)];
-  // column sp of J_P = [c -s; s c]' ... row-rotation coefficients of the update: side 0: (c, -s), side 1: (s, c)
-  const real u0 = sp ? P.s : P.c, u1 = sp ? P.c : -P.s;
-  const real v0 = sq ? Q.s : Q.c, v1 = sq ? Q.c : -Q.s;
-  const real ra = u0 * b11 + u1 * b21, rb = u0 * b12 + u1 * b22;
-  const real apq = v0 * ra + v1 * rb;
-  const real app = app0 + (sp ? P.t : -P.t) * pxy;
-  const real aqq = aqq0 + (sq ? Q.t : -Q.t) * qxy;
-  return psd_make_rotation(apq, app, aqq, p, q, k, thr, offmax, out);
+  PsdLaPlan pl;
+  psd_la_prepare(pl, P, Q, p, q, ld);
+  return psd_la_finish(A, pl, k, thr, offmax, out);
 }
 // which pairs of step s hold the players of pair i of step s + 1 (circle method, see the header)
 PSD_HD int psd_source_of_p(int i, int npairs) { return i == 0 ? 0 : (i == npairs - 1 ? npairs - 1 : i + 1); }
