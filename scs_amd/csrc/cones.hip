@@ -453,7 +453,10 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   RotCS *rot_cs = reinterpret_cast<RotCS *>(smem_raw);
   int2 *rot_pq = reinterpret_cast<int2 *>(rot_cs + PSD_MAX_PAIRS);
   real *red = reinterpret_cast<real *>(rot_pq + PSD_MAX_PAIRS);
-  volatile int *rot_any = reinterpret_cast<volatile int *>(red + 8); // [2]: does step (parity) rotate at all?
+  // [2]: does step (parity) rotate at all?  NOT volatile: LLVM leaves volatile accesses in the generic address space, i.e. FLAT
+  // loads / stores (flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0)) with vector-memory latency on the critical path of EVERY step --
+  // rounds 2-4 paid that in the two-phase step too.  Every write and its reads are separated by a workgroup barrier.
+  int *rot_any = reinterpret_cast<int *>(red + 8);
   real *lds_mat = red + 10;
   const int cone = blockIdx.x, tid = threadIdx.x;
   // psd_k > 0: real symmetric block of that order (packed lower triangle).

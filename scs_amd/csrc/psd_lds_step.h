@@ -266,7 +266,12 @@ PSD_HD void psd_la_prepare(PsdLaPlan &pl, const PsdRot &P, const PsdRot &Q, int 
 }
 PSD_HD bool psd_la_finish(const real *A, const PsdLaPlan &pl, int k, real thr, real &offmax, PsdRot &out) {
   const real b11 = A[pl.a[0]], b12 = A[pl.a[1]], b21 = A[pl.a[2]], b22 = A[pl.a[3]];
-  const real app0 = A[pl.a[4]], aqq0 = A[pl.a[5]], pxy = A[pl.a[6]], qxy = A[pl.a[7]];
+  real app0 = A[pl.a[4]], aqq0 = A[pl.a[5]], pxy = A[pl.a[6]], qxy = A[pl.a[7]];
+#ifndef PSD_STEP_HOST_CHECK
+  // all eight reads are issued together: left alone the compiler sinks the four diagonal reads into the "rotates" branch of
+  // psd_make_rotation -- a second LDS round trip behind the first on the chain that bounds the step
+  asm volatile("" : "+v"(app0), "+v"(aqq0), "+v"(pxy), "+v"(qxy));
+#endif
   const real ra = pl.u0 * b11 + pl.u1 * b21, rb = pl.u0 * b12 + pl.u1 * b22;
   const real apq = pl.v0 * ra + pl.v1 * rb;
   const real app = app0 + pl.tp * pxy;
