@@ -50,6 +50,7 @@ struct LinSys {
   int nt_mode = 0;        // non-temporal policy of the update kernel's streams (SCS_AMD_VEC_NT; 0 = default policy; bit 2: two chunks per lane in flight)
   int dir_mode = 0;       // k_cg_direction: bit 0 non-temporal z reads, bit 1 non-temporal p stores, bit 2 two chunks per lane (SCS_AMD_DIR_MODE)
   bool use_cg2 = false;   // two launches per CG iteration (n <= CG2_N_MAX): k_cg2_a + transposed product
+  bool use_cg3 = false;   // three launches per CG iteration (round 5): the stop test, alpha, beta, x, r, z, p in ONE vector kernel (k_cg3_update)
 
   CsrDev At; // CSR(A') == CSC(A): n rows, gathers an m-vector
   CsrDev A;  // CSR(A): m rows, gathers an n-vector
@@ -61,6 +62,7 @@ struct LinSys {
   DevBuf<real> p2, r2;               // second direction / residual buffers of the two-launch path (p_j, r_j in {p, p2}[j & 1])
   DevBuf<real> tmp;                  // m
   DevBuf<real> partA, partB;         // reduction partials
+  DevBuf<real> partC, partD;         // use_cg3: partials of z'Gp and Gp'MGp
   DevBuf<CgCtl> ctl;
   PinnedBuf<CgCtl> hctl;
 
@@ -74,6 +76,7 @@ struct LinSys {
   bool cg_graph_tried = false, use_graph = false;
   void enqueue_cg_iteration(int q);
   void enqueue_cg2_iteration(long long it);
+  void enqueue_cg3_iteration(long long it);
   bool build_cg_graph();
   // statistics / profiling
   long long tot_cg_its = 0, n_solves = 0, n_matvecs = 0, n_spmv = 0, n_graph_launches = 0;

@@ -342,6 +342,130 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg_direction(real *p, const re
   }
 }
 
+// ----------------------------------------------------------------------------
+// Three kernels per CG iteration (round 5): K1, K2 as before, then ONE vector kernel that does what k_cg_update AND
+// k_cg_direction did.  private.c:181-214 needs two reductions per iteration -- p'Gp for alpha, then z'r of the NEW residual for beta --
+// and the second one is what forced a second launch.  It follows from quantities the K2 epilogue can sum while it has Gp in hand:
+//     z_new' r_new = sum M (r - alpha Gp)^2 = z'r - 2 alpha (z'Gp) + alpha^2 (Gp' M Gp)
+// (EPI_GP3 leaves the partials of p'Gp, z'Gp = sum M r Gp and Gp'MGp), so this kernel knows alpha AND beta before it touches a vector and
+// streams  x += alpha p;  r -= alpha Gp;  z = M r;  p = z + beta p  in one pass -- z is never stored (8 instead of 11 vector passes).
+// The expansion is used for beta ONLY: the z'r that the NEXT alpha divides is summed directly from the new residual in this pass (partials,
+// as before), so its cancellation error (~eps z'r_old / z'r_new, relative) never accumulates; it perturbs the search direction at rounding
+// level, like a different summation order.  The stop test of private.c:202 for the residual this launch produces is evaluated by the NEXT
+// launch (from this one's |r| partials): the iterate returned is exactly the first one with |r|_inf < tol, the iteration count is the
+// reference's; what it costs is one matrix product enqueued past convergence per solve (~1 % at ~118 iterations per solve).
+// `it` = iterations completed before this launch.  Partials double-buffered by the parity of `it`.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg3_update(real *x, real *r, real *p, const real *__restrict__ Gp,
+                                                             const real *__restrict__ M, int n, const real *part_pgp,
+                                                             const real *part_d1, const real *part_d2, int cnt_sp,
+                                                             const real *part_ztr_prev, const real *part_max_prev, int cnt_v,
+                                                             real *part_ztr, real *part_max, CgCtl *ctl, int it) {
+  __shared__ real red[4];
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+  const int nv = n / RVW;
+  const bool has = gtid < nv;
+  rvec P0 = {}, G0 = {}, M0 = {}, X0 = {}, R0 = {};
+  if (has) { // the lane's first chunk travels with the scalars (one round trip, as in k_cg_update)
+    P0 = ldv(p, gtid);
+    G0 = ldv(Gp, gtid);
+    M0 = ldv_nt(M, gtid);
+    X0 = ldv_nt(x, gtid);
+    R0 = ldv_nt(r, gtid);
+  }
+  const int done = ctl->cg_done, max_its = ctl->max_its;
+  const real tol = ctl->tol;
+  real ztr = ctl->ztr[0];
+  real s0 = 0, s1 = 0, s2 = 0, zs = 0, ms = 0;
+  for (int i = threadIdx.x; i < cnt_sp; i += blockDim.x) {
+    s0 += part_pgp[i];
+    s1 += part_d1[i];
+    s2 += part_d2[i];
+  }
+  if (it > 0)
+    for (int i = threadIdx.x; i < cnt_v; i += blockDim.x) {
+      zs += part_ztr_prev[i];
+      const real v = part_max_prev[i];
+      ms = v > ms ? v : ms;
+    }
+  if (done) return;
+  const real pgp = block_sum(s0, red), d1 = block_sum(s1, red), d2 = block_sum(s2, red);
+  bool conv = false;
+  real nr = 0;
+  if (it > 0) { // the stop test for the residual the previous launch produced (private.c:202)
+    ztr = block_sum(zs, red);
+    nr = block_max(ms, red);
+    conv = nr < tol;
+  }
+  const bool brk = !conv && ztr == (real)0; // private.c:206
+  const bool stop = conv || brk || it >= max_its;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (it > 0) {
+      ctl->norm_r = nr;
+      ctl->ztr[0] = ztr;
+      ctl->iters = it; // converged after `it` iterations -> it; breakdown in iteration `it` -> it (private.c:203,216)
+    }
+    if (stop) ctl->cg_done = 1;
+  }
+  if (stop) return;
+  const real alpha = ztr / pgp;
+  const real ztr_new = ztr + alpha * (alpha * d2 - (real)2 * d1);
+  const real beta = ztr_new / ztr;
+  real zo = 0, mx = 0;
+  if (has) {
+#pragma unroll
+    for (int e = 0; e < RVW; ++e) {
+      X0.v[e] += alpha * P0.v[e];
+      const real ri = R0.v[e] + (-alpha) * G0.v[e];
+      R0.v[e] = ri;
+      const real zi = ri * M0.v[e];
+      P0.v[e] = zi + beta * P0.v[e];
+      zo += zi * ri;
+      const real a = absval(ri);
+      mx = a > mx ? a : mx;
+    }
+    stv_nt(x, gtid, X0);
+    stv_nt(r, gtid, R0);
+    stv(p, gtid, P0);
+  }
+  for (int iv = gtid + gs; iv < nv; iv += gs) { // 16 B per lane per array; x, r, M are streamed once per iteration: non-temporal
+    rvec P = ldv(p, iv);
+    const rvec G = ldv(Gp, iv), Mv = ldv_nt(M, iv);
+    rvec X = ldv_nt(x, iv), R = ldv_nt(r, iv);
+#pragma unroll
+    for (int e = 0; e < RVW; ++e) {
+      X.v[e] += alpha * P.v[e];
+      const real ri = R.v[e] + (-alpha) * G.v[e];
+      R.v[e] = ri;
+      const real zi = ri * Mv.v[e];
+      P.v[e] = zi + beta * P.v[e];
+      zo += zi * ri;
+      const real a = absval(ri);
+      mx = a > mx ? a : mx;
+    }
+    stv_nt(x, iv, X);
+    stv_nt(r, iv, R);
+    stv(p, iv, P);
+  }
+  for (int i = nv * RVW + gtid; i < n; i += gs) {
+    const real pi = p[i];
+    x[i] += alpha * pi;
+    const real ri = r[i] + (-alpha) * Gp[i];
+    r[i] = ri;
+    const real zi = ri * M[i];
+    p[i] = zi + beta * pi;
+    zo += zi * ri;
+    const real a = absval(ri);
+    mx = a > mx ? a : mx;
+  }
+  zo = block_sum(zo, red);
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) {
+    part_ztr[blockIdx.x] = zo;
+    part_max[blockIdx.x] = mx;
+  }
+}
+
 // p'Gp partials (sharded solve: the dot product can only be taken after the all-reduce that completes Gp)
 __global__ __launch_bounds__(SCSAMD_BLOCK) void k_dot_partial(const real *__restrict__ a, const real *__restrict__ b, int n,
                                                               real *part, const int *skip) {
@@ -757,6 +881,7 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
     case EPI_GP: WR_LAUNCH(EPI_GP); break;
     case EPI_ACC: WR_LAUNCH(EPI_ACC); break;
     case EPI_NEGDIV: WR_LAUNCH(EPI_NEGDIV); break;
+    case EPI_GP3: WR_LAUNCH(EPI_GP3); break;
     default: throw HipError("scs_amd: bad spmv epilogue");
     }
 #undef WR_LAUNCH
@@ -922,6 +1047,14 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
     const bool no_wave = !(A.wave && A.wave->built) && !(At.wave && At.wave->built);
     use_cg2 = !use_fused && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
     if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
+    // three launches per CG iteration (k_cg3_update): wherever the transposed product runs through the wave-owned-rows kernels (their
+    // epilogue carries the two extra dot products) and the iterations are not replayed from a graph; SCS_AMD_CG3 = 0 | 1
+    // (fp64 only: in fp32 the expansion behind beta loses ~eps x 10..100 relative, which is the size of fp32 CG's own rounding -- not worth
+    // a 2 % shorter iteration there)
+    const bool cg3_ok = sizeof(real) == 8 && !use_fused && !use_cg2 && At.wave && At.wave->built && vec_grid(n) <= PART_CAP / 4;
+    use_cg3 = cg3_ok && !use_graph;
+    if (const char *e = getenv("SCS_AMD_CG3")) use_cg3 = atoi(e) != 0 && cg3_ok;
+    if (use_cg3) use_graph = false;
     if (use_cg2) {
       p2.alloc(n);
       r2.alloc(n);
@@ -939,6 +1072,10 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
   tmp.alloc(m);
   partA.alloc(PART_CAP);
   partB.alloc(PART_CAP);
+  if (use_cg3) {
+    partC.alloc(PART_CAP);
+    partD.alloc(PART_CAP);
+  }
   ctl.alloc(1);
   hctl.alloc(1);
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -960,6 +1097,7 @@ void LinSys::set_shard(ShardHook *h) {
     if (has_P) throw HipError("scs_amd: a row-sharded system with P is not supported");
     use_fused = false;
     use_cg2 = false;
+    use_cg3 = false;
     use_graph = false;
   }
 }
@@ -1073,6 +1211,30 @@ void LinSys::enqueue_cg_iteration(int q) {
                      gv, c, q, dir_mode);
 }
 
+// three-kernel iteration (k_cg3_update): K1, [P p], K2 with the three dot products in its epilogue, the fused vector kernel
+void LinSys::enqueue_cg3_iteration(long long it) {
+  CgCtl *c = ctl.p;
+  const int gv = vec_grid(n);
+  const int gAt = At.wave->grid();
+  const int q = (int)(it & 1);
+  real *ztr_cur = partB.p + q * (PART_CAP / 4), *max_cur = partB.p + PART_CAP / 2 + q * (PART_CAP / 4);
+  real *ztr_prev = partB.p + (q ^ 1) * (PART_CAP / 4), *max_prev = partB.p + PART_CAP / 2 + (q ^ 1) * (PART_CAP / 4);
+  EpiArgs e1{ry.p, nullptr, nullptr, nullptr};
+  launch_spmv(EPI_DIV, A, p.p, tmp.p, e1, &c->cg_done);
+  if (has_P) {
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr};
+    launch_spmv(EPI_PLAIN, P, p.p, Pp.p, ep, &c->cg_done);
+  }
+  EpiArgs e2{rx.p, p.p, has_P ? Pp.p : nullptr, partA.p};
+  e2.mv = M.p;
+  e2.rv = r.p;
+  e2.partial2 = partC.p;
+  e2.partial3 = partD.p;
+  launch_spmv(EPI_GP3, At, tmp.p, Gp.p, e2, &c->cg_done);
+  hipLaunchKernelGGL(k_cg3_update, dim3(gv), dim3(SCSAMD_BLOCK), 0, stream, cg_x, r.p, p.p, Gp.p, M.p, n, partA.p, partC.p, partD.p, gAt,
+                     ztr_prev, max_prev, gv, ztr_cur, max_cur, c, (int)std::min<long long>(it, 2147483647LL));
+}
+
 // Capture CG_GRAPH_ITERS iterations into an executable graph.  Any failure leaves cg_graph null
 // and the loop keeps launching kernels one by one (same kernels, same order).
 bool LinSys::build_cg_graph() {
@@ -1182,7 +1344,8 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
   if (use_graph && !profiling && !cg_graph_tried) build_cg_graph();
   for (;;) {
     // cg2: the update/direction of iteration j runs inside iteration j+1's first kernel, so one more is enqueued
-    int nb = (int)std::min<long long>(batch, max_its + (use_cg2 ? 1 : 0) - it);
+    const int extra = (use_cg2 || use_cg3) ? 1 : 0; // the launch that evaluates the last iteration's stop test
+    int nb = (int)std::min<long long>(batch + (use_cg3 ? 1 : 0), max_its + extra - it);
     if (nb < 1) nb = 1;
     if (cg_graph && !profiling) {
       // whole graphs only (the parity of the double-buffered z'r slot restarts with each graph);
@@ -1194,6 +1357,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
     } else {
       for (int j = 0; j < nb; ++j) {
         if (use_cg2) enqueue_cg2_iteration(it + j);
+        else if (use_cg3) enqueue_cg3_iteration(it + j);
         else enqueue_cg_iteration((int)((it + j) & 1));
       }
     }
@@ -1204,7 +1368,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
       fprintf(stderr, "[scs_amd pcg] enq=%lld iters=%d done=%d zero=%d |r|=%.3e tol=%.3e ztr=(%.3e,%.3e) |b|=%.3e\n",
               it, hctl.p->iters, hctl.p->cg_done, hctl.p->zero_rhs, (double)hctl.p->norm_r,
               (double)hctl.p->tol, (double)hctl.p->ztr[0], (double)hctl.p->ztr[1], (double)hctl.p->rhs_norm);
-    if (hctl.p->cg_done || it >= max_its + (use_cg2 ? 1 : 0)) break;
+    if (hctl.p->cg_done || it >= max_its + extra) break;
     batch = std::max(4, std::min(last_its / 4 + 1, 1024));
   }
   const int its = hctl.p->iters;

@@ -47,6 +47,7 @@ enum {
   EPI_GP = 2,     // y[r] = (y0[r] + acc) + d[r] * xin[r];  partial dot xin.y
   EPI_ACC = 3,    // y[r] = y[r] + acc  (sum starts at y[r], like the reference)
   EPI_NEGDIV = 4, // y[r] = (-y[r] + acc) / d[r]            (y = R_y^-1 (A x - r_y))
+  EPI_GP3 = 5,    // EPI_GP plus the partial sums of (M r) . y and y . (M y): the three-kernel PCG iteration (linsys.hip, k_cg3_update)
 };
 
 struct EpiArgs {
@@ -54,12 +55,16 @@ struct EpiArgs {
   const real *xin; // EPI_GP: the vector being multiplied (p), length rows
   const real *y0;  // EPI_GP: optional initial value (P p) or nullptr
   real *partial;   // EPI_GP: per-workgroup partial of xin . y, or nullptr
+  const real *mv = nullptr;  // EPI_GP3: the Jacobi preconditioner M (length rows)
+  const real *rv = nullptr;  // EPI_GP3: the residual r
+  real *partial2 = nullptr;  // EPI_GP3: per-workgroup partial of sum M r y
+  real *partial3 = nullptr;  // EPI_GP3: per-workgroup partial of sum M y y
 };
 
 #ifdef __HIPCC__
 template <int EPI>
 __device__ __forceinline__ real epi_init(const EpiArgs &e, const real *y, int r) {
-  if (EPI == EPI_GP) return e.y0 ? e.y0[r] : (real)0;
+  if (EPI == EPI_GP || EPI == EPI_GP3) return e.y0 ? e.y0[r] : (real)0;
   if (EPI == EPI_ACC) return y[r];
   if (EPI == EPI_NEGDIV) return -y[r];
   return (real)0;
@@ -75,6 +80,18 @@ __device__ __forceinline__ real epi_apply(const EpiArgs &e, real *y, int r, real
   }
   y[r] = out;
   return out;
+}
+
+// EPI_GP3: y[r] = acc + d[r] xin[r] as EPI_GP, and the three dot products the fused update needs:
+//   dot += xin y (= p'Gp),  d1 += (M r) y (= z'Gp),  d2 += y (M y)
+__device__ __forceinline__ void epi_apply3(const EpiArgs &e, real *y, int r, real acc, real &dot, real &d1, real &d2) {
+  const real xr = e.xin[r];
+  const real out = acc + e.d[r] * xr;
+  const real t = e.mv[r] * out;
+  dot += xr * out;
+  d1 += e.rv[r] * t;
+  d2 += out * t;
+  y[r] = out;
 }
 
 // epilogue with the row's operands already in registers (same arithmetic as epi_apply)

@@ -76,6 +76,38 @@ __device__ __forceinline__ void wr_consume(const WaveView &A, const WrChunk &c, 
     if (eb + i < t) lds_add(acc + (w[i] >> A.cbits), c.v[i] * xx[i]);
 }
 
+// one partial per workgroup and dot product: waves in a fixed order (bit-reproducible)
+template <int EPI, int WPB>
+__device__ __forceinline__ void wr_block_partials(const EpiArgs &e, real (*red)[WPB], real dot, real d1, real d2, int wave, int lane) {
+  dot = wave_sum(dot);
+  if (EPI == EPI_GP3) {
+    d1 = wave_sum(d1);
+    d2 = wave_sum(d2);
+  }
+  if (lane == 0) {
+    red[0][wave] = dot;
+    if (EPI == EPI_GP3) {
+      red[1][wave] = d1;
+      red[2][wave] = d2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    real sum = red[0][0];
+    for (int i = 1; i < WPB; ++i) sum += red[0][i];
+    e.partial[blockIdx.x] = sum;
+    if (EPI == EPI_GP3) {
+      real s1 = red[1][0], s2 = red[2][0];
+      for (int i = 1; i < WPB; ++i) {
+        s1 += red[1][i];
+        s2 += red[2][i];
+      }
+      e.partial2[blockIdx.x] = s1;
+      e.partial3[blockIdx.x] = s2;
+    }
+  }
+}
+
 // (Round 4, measured and not kept: an "x-window prefetch" instantiation -- every wave loads its share of the window of x the chip will
 // gather from 1..6 chunks later, next to its stream loads, so that the gathers hit L2 instead of pulling each line of x out of the
 // Infinity Cache once per XCD: 70.9 us per product at a look-ahead of 1 chunk, 77.5 - 79.8 us at 2 - 6, against 68.2 - 68.8 us
@@ -93,11 +125,11 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
                                                             const int *skip, int accrows) {
   if (skip && *skip) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char wr_smem[];
-  __shared__ real red[WR_WPB];
+  __shared__ real red[3][WR_WPB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   real *acc = reinterpret_cast<real *>(wr_smem) + (size_t)wave * accrows;
   const unsigned cmask = (1u << A.cbits) - 1;
-  real dot = 0;
+  real dot = 0, d1 = 0, d2 = 0;
   for (int u = blockIdx.x * WR_WPB + wave; u < A.nunit; u += gridDim.x * WR_WPB) {
     const int r0 = A.urow[u], nr = A.urow[u + 1] - r0;
     const int s = A.useg[2 * u], t = A.useg[2 * u + 1];
@@ -122,19 +154,11 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
     }
     for (int k = lane; k < nr; k += 64) {
       const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
-      epi_apply<EPI>(e, y, r0 + k, a, dot);
+      if (EPI == EPI_GP3) epi_apply3(e, y, r0 + k, a, dot, d1, d2);
+      else epi_apply<EPI>(e, y, r0 + k, a, dot);
     }
   }
-  if (EPI == EPI_GP && e.partial) {
-    dot = wave_sum(dot);
-    if (lane == 0) red[wave] = dot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      real sum = red[0];
-      for (int i = 1; i < WR_WPB; ++i) sum += red[i];
-      e.partial[blockIdx.x] = sum;
-    }
-  }
+  if ((EPI == EPI_GP || EPI == EPI_GP3) && e.partial) wr_block_partials<EPI, WR_WPB>(e, red, dot, d1, d2, wave, lane);
 }
 // Lockstep instantiation (round 4; the library's choice for fp64 systems from 5e6 nonzeros on, SCS_AMD_WR_LOCKSTEP = 0 | 1 forces either): ONE
 // workgroup of 16 waves per CU, one unit per wave (units half as long as the plain kernel's).  The host stores every 256-entry chunk so that
@@ -154,12 +178,12 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
                                                                         const int *skip, int accrows) {
   if (skip && *skip) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char wr_smem[];
-  __shared__ real red[WL_WPB];
+  __shared__ real red[3][WL_WPB];
   __shared__ int s_nch[WL_WPB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   real *acc = reinterpret_cast<real *>(wr_smem) + (size_t)wave * accrows;
   const unsigned cmask = (1u << A.cbits) - 1;
-  real dot = 0;
+  real dot = 0, d1 = 0, d2 = 0;
   const int per_round = gridDim.x * WL_WPB;
   const int nround = (A.nunit + per_round - 1) / per_round;
   for (int rd = 0; rd < nround; ++rd) {
@@ -204,20 +228,12 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
     }
     for (int k = lane; k < nr; k += 64) {
       const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
-      epi_apply<EPI>(e, y, r0 + k, a, dot);
+      if (EPI == EPI_GP3) epi_apply3(e, y, r0 + k, a, dot, d1, d2);
+      else epi_apply<EPI>(e, y, r0 + k, a, dot);
     }
     __syncthreads(); // s_nch is rewritten by the next round
   }
-  if (EPI == EPI_GP && e.partial) {
-    dot = wave_sum(dot);
-    if (lane == 0) red[wave] = dot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      real sum = red[0];
-      for (int i = 1; i < WL_WPB; ++i) sum += red[i];
-      e.partial[blockIdx.x] = sum;
-    }
-  }
+  if ((EPI == EPI_GP || EPI == EPI_GP3) && e.partial) wr_block_partials<EPI, WL_WPB>(e, red, dot, d1, d2, wave, lane);
 }
 #endif // __HIPCC__
 

@@ -65,6 +65,17 @@ def test_exact_cg_trajectory_parity(n, m, col_nnz, seed, over, q_fixed):
         assert d <= REL, (v, d)
 
 
+@pytest.mark.parametrize("n,m,col_nnz,seed,over,q_fixed", [CASES[1], CASES[4]])
+def test_exact_cg_trajectory_parity_through_the_three_kernel_iteration(monkeypatch, n, m, col_nnz, seed, over, q_fixed):
+    """the same 1e-6 trajectory bar with the PCG loop of the large systems forced on at a size the reference solves in seconds: wave-owned-
+    rows products (SCS_AMD_WAVEROWS=1), no graph replay, k_cg3_update (SCS_AMD_CG3=1: stop test, alpha, beta and the vector updates in one
+    launch, beta from the expanded z'r)"""
+    monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")
+    monkeypatch.setenv("SCS_AMD_GRAPH", "0")
+    monkeypatch.setenv("SCS_AMD_CG3", "1")
+    test_exact_cg_trajectory_parity(n, m, col_nnz, seed, over, q_fixed)
+
+
 @pytest.mark.parametrize("n,m,col_nnz,seed,over,q_fixed", CASES[:5])
 def test_default_schedule_same_optimum(n, m, col_nnz, seed, over, q_fixed):
     ref = _ref()
