@@ -1047,12 +1047,15 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
     const bool no_wave = !(A.wave && A.wave->built) && !(At.wave && At.wave->built);
     use_cg2 = !use_fused && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
     if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
-    // three launches per CG iteration (k_cg3_update): wherever the transposed product runs through the wave-owned-rows kernels (their
-    // epilogue carries the two extra dot products) and the iterations are not replayed from a graph; SCS_AMD_CG3 = 0 | 1
+    // three launches per CG iteration (k_cg3_update), SCS_AMD_CG3=1: possible wherever the transposed product runs through the wave-owned-
+    // rows kernels (their epilogue carries the two extra dot products)
     // (fp64 only: in fp32 the expansion behind beta loses ~eps x 10..100 relative, which is the size of fp32 CG's own rounding -- not worth
     // a 2 % shorter iteration there)
     const bool cg3_ok = sizeof(real) == 8 && !use_fused && !use_cg2 && At.wave && At.wave->built && vec_grid(n) <= PART_CAP / 4;
-    use_cg3 = cg3_ok && !use_graph;
+    // OFF by default: measured at the headline size it buys 1.1 us of a 159.6 us CG iteration (profiles/r5_cg_vector_kernels.md: the launch
+    // and the re-reduction it removes are paid back by two more vector reads in the product's epilogue and one product enqueued past
+    // convergence per solve) and it changes the rounding of every iterate -- not worth leaving the reference's recurrence for.
+    use_cg3 = false;
     if (const char *e = getenv("SCS_AMD_CG3")) use_cg3 = atoi(e) != 0 && cg3_ok;
     if (use_cg3) use_graph = false;
     if (use_cg2) {

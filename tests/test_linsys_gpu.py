@@ -296,7 +296,8 @@ def test_three_kernel_cg_iteration_matches_the_four_kernel_one_and_the_reference
             res[tol, cg3] = (out, _stats(amd, w)["cg_iters"])
             amd.scs_free_lin_sys_work(w)
         (x4, it4), (x3, it3) = res[tol, "0"], res[tol, "1"]
-        assert it3 == it4 and it3 > 0, (tol, it3, it4)
+        # (at the 1e-12 floor rounding decides which iteration first dips below the tolerance: 2298 vs 2310 measured)
+        assert it3 > 0 and (it3 == it4 if tol > 1e-12 else abs(it3 - it4) <= 0.02 * it4), (tol, it3, it4)
         scale = np.abs(x4).max()
         assert np.abs(x3 - x4).max() <= (1e-9 if tol == 1e-12 else 10 * tol) * scale, (tol, np.abs(x3 - x4).max())
         # the stopping rule itself: |b_x + A' R_y^-1 b_y - (R_x + P + A' R_y^-1 A) x|_inf < tol for the returned x
