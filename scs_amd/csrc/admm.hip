@@ -448,7 +448,8 @@ static int validate_problem(const ScsData *d, const ScsCone *k, const ScsSetting
   }
   if (!fits_int32(d->A) || !fits_int32(d->P) || (long long)d->m + (long long)d->n + 1 > 2147483647LL) {
     // only a -DDLONG caller can get here: the device indexes with 32 bits
-    printf("problem too large for 32-bit device indexing (m + n + 1 and nnz must stay below 2^31)\n");
+    printf(sizeof(eoff) == 8 ? "problem too large for the device indexing (m + n + 1 must stay below 2^31)\n"
+                             : "problem too large for 32-bit device indexing (m + n + 1 and nnz must stay below 2^31; the DLONG build carries 64-bit entry positions)\n");
     return -1;
   }
   if (validate_csc(d->A, d->m, d->n, false, "A") < 0) return -1;

@@ -24,6 +24,16 @@
 
 namespace scsamd {
 
+// Position of an entry in the value / index arrays of a sparse matrix (row pointers, unit entry ranges, CSC positions).  32-bit
+// like every other index -- except in the DLONG build (64-bit scs_int at the ABI, include/scs_types.h:13-20), where a matrix may
+// hold 2^31 nonzeros or more (24 GB of CSR per orientation against 288 GB of HBM).  Column / row INDICES stay 32-bit in both
+// builds (m, n < 2^31).  Round 5.
+#ifdef DLONG
+typedef long long eoff;
+#else
+typedef int eoff;
+#endif
+
 #define SCSAMD_WAVE 64
 #define SCSAMD_BLOCK 256
 

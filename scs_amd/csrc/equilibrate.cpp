@@ -64,13 +64,13 @@ static void ruiz_pass(const HostCsc *P, const HostCsc &A, const std::vector<int>
   const int m = A.m, n = A.n;
   std::fill(Dt.begin(), Dt.end(), (real)0);
   for (int j = 0; j < n; ++j)
-    for (int k = A.p[j]; k < A.p[j + 1]; ++k) Dt[A.i[k]] = std::max(Dt[A.i[k]], (real)std::fabs(A.x[k]));
+    for (eoff k = A.p[j]; k < A.p[j + 1]; ++k) Dt[A.i[k]] = std::max(Dt[A.i[k]], (real)std::fabs(A.x[k]));
   aggregate_over_cones(seg, Dt, AGG_MAX);
   for (int i = 0; i < m; ++i) Dt[i] = safe_div_pos((real)1, std::sqrt(limit_scale(Dt[i])));
   std::fill(Et.begin(), Et.end(), (real)0);
   if (P)
     for (int j = 0; j < n; ++j)
-      for (int k = P->p[j]; k < P->p[j + 1]; ++k) {
+      for (eoff k = P->p[j]; k < P->p[j + 1]; ++k) {
         const int i = P->i[k];
         const real w = std::fabs(P->x[k]);
         Et[j] = std::max(Et[j], w);
@@ -78,7 +78,7 @@ static void ruiz_pass(const HostCsc *P, const HostCsc &A, const std::vector<int>
       }
   for (int j = 0; j < n; ++j) {
     real cn = 0;
-    for (int k = A.p[j]; k < A.p[j + 1]; ++k) cn = std::max(cn, (real)std::fabs(A.x[k]));
+    for (eoff k = A.p[j]; k < A.p[j + 1]; ++k) cn = std::max(cn, (real)std::fabs(A.x[k]));
     Et[j] = std::max(Et[j], cn);
     Et[j] = safe_div_pos((real)1, std::sqrt(limit_scale(Et[j])));
   }
@@ -89,14 +89,14 @@ static void l2_pass(const HostCsc *P, const HostCsc &A, const std::vector<int> &
   const int m = A.m, n = A.n;
   std::fill(Dt.begin(), Dt.end(), (real)0);
   for (int j = 0; j < n; ++j)
-    for (int k = A.p[j]; k < A.p[j + 1]; ++k) Dt[A.i[k]] += A.x[k] * A.x[k];
+    for (eoff k = A.p[j]; k < A.p[j + 1]; ++k) Dt[A.i[k]] += A.x[k] * A.x[k];
   for (int i = 0; i < m; ++i) Dt[i] = std::sqrt(Dt[i]);
   aggregate_over_cones(seg, Dt, AGG_MEAN);
   for (int i = 0; i < m; ++i) Dt[i] = safe_div_pos((real)1, std::sqrt(limit_scale(Dt[i])));
   std::fill(Et.begin(), Et.end(), (real)0);
   if (P)
     for (int j = 0; j < n; ++j)
-      for (int k = P->p[j]; k < P->p[j + 1]; ++k) {
+      for (eoff k = P->p[j]; k < P->p[j + 1]; ++k) {
         const int i = P->i[k];
         const real w = P->x[k] * P->x[k];
         Et[j] += w;
@@ -104,7 +104,7 @@ static void l2_pass(const HostCsc *P, const HostCsc &A, const std::vector<int> &
       }
   for (int j = 0; j < n; ++j) {
     real ss = 0;
-    for (int k = A.p[j]; k < A.p[j + 1]; ++k) ss += A.x[k] * A.x[k];
+    for (eoff k = A.p[j]; k < A.p[j + 1]; ++k) ss += A.x[k] * A.x[k];
     Et[j] += ss;
     Et[j] = safe_div_pos((real)1, std::sqrt(limit_scale(std::sqrt(Et[j]))));
   }
@@ -114,12 +114,12 @@ static void apply_scaling(HostCsc *P, HostCsc &A, const std::vector<real> &Dt, c
                           Scaling &sc) {
   for (int j = 0; j < A.n; ++j) {
     const real ej = Et[j];
-    for (int k = A.p[j]; k < A.p[j + 1]; ++k) A.x[k] *= Dt[A.i[k]] * ej;
+    for (eoff k = A.p[j]; k < A.p[j + 1]; ++k) A.x[k] *= Dt[A.i[k]] * ej;
   }
   if (P)
     for (int j = 0; j < P->n; ++j) {
       const real ej = Et[j];
-      for (int k = P->p[j]; k < P->p[j + 1]; ++k) P->x[k] *= Et[P->i[k]] * ej;
+      for (eoff k = P->p[j]; k < P->p[j + 1]; ++k) P->x[k] *= Et[P->i[k]] * ej;
     }
   for (int i = 0; i < A.m; ++i) sc.D[i] *= Dt[i];
   for (int j = 0; j < A.n; ++j) sc.E[j] *= Et[j];
@@ -211,7 +211,7 @@ int validate_csc(const ScsMatrix *M, int rows, int cols, bool upper_only, const 
   }
   if (upper_only)
     for (int j = 0; j < cols; ++j)
-      for (int k = M->p[j]; k < M->p[j + 1]; ++k)
+      for (eoff k = M->p[j]; k < M->p[j + 1]; ++k)
         if (M->i[k] > j) {
           printf("error: P is not upper triangular\n");
           return -1;

@@ -40,11 +40,11 @@ __device__ __forceinline__ real d_inv_sqrt_scale(real v) { return d_safe_div_pos
 // MODE 0: max |x| per row; MODE 1: sqrt(sum x^2) per row.  One lane per row.
 template <int MODE>
 __global__ void __launch_bounds__(SCSAMD_BLOCK)
-k_row_stat(const int *__restrict__ rp, const real *__restrict__ rx, int rows, real *__restrict__ out) {
+k_row_stat(const eoff *__restrict__ rp, const real *__restrict__ rx, int rows, real *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   real acc = 0;
-  for (int k = rp[i]; k < rp[i + 1]; ++k) {
+  for (eoff k = rp[i]; k < rp[i + 1]; ++k) {
     const real v = rx[k];
     if (MODE == 0) acc = fmax(acc, fabs(v));
     else acc += v * v;
@@ -82,20 +82,20 @@ __global__ void __launch_bounds__(SCSAMD_BLOCK) k_inv_sqrt_scale(real *__restric
 // the full symmetric P, then E_j = 1/sqrt(clip(.))
 template <int MODE>
 __global__ void __launch_bounds__(SCSAMD_BLOCK)
-k_col_stat(const int *__restrict__ cp, const real *__restrict__ cx, const int *__restrict__ pp,
+k_col_stat(const eoff *__restrict__ cp, const real *__restrict__ cx, const eoff *__restrict__ pp,
            const real *__restrict__ px, int cols, real *__restrict__ Et) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
   real e = 0;
   if (pp) {
-    for (int k = pp[j]; k < pp[j + 1]; ++k) {
+    for (eoff k = pp[j]; k < pp[j + 1]; ++k) {
       const real v = px[k];
       if (MODE == 0) e = fmax(e, fabs(v));
       else e += v * v;
     }
   }
   real a = 0;
-  for (int k = cp[j]; k < cp[j + 1]; ++k) {
+  for (eoff k = cp[j]; k < cp[j + 1]; ++k) {
     const real v = cx[k];
     if (MODE == 0) a = fmax(a, fabs(v));
     else a += v * v;
@@ -108,12 +108,12 @@ k_col_stat(const int *__restrict__ cp, const real *__restrict__ cx, const int *_
 // x[k] *= outer[major] * inner[minor_index[k]]; written so that the product of the two
 // scale factors is formed first, as the host does (A.x[k] *= Dt[i] * Et[j])
 __global__ void __launch_bounds__(SCSAMD_BLOCK)
-k_rescale(const int *__restrict__ ptr, const int *__restrict__ idx, real *__restrict__ x, int majors,
+k_rescale(const eoff *__restrict__ ptr, const int *__restrict__ idx, real *__restrict__ x, int majors,
           const real *__restrict__ s_major, const real *__restrict__ s_minor) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= majors) return;
   const real sj = s_major[j];
-  for (int k = ptr[j]; k < ptr[j + 1]; ++k) {
+  for (eoff k = ptr[j]; k < ptr[j + 1]; ++k) {
     const real f = s_minor[idx[k]] * sj;
     x[k] *= f;
   }
@@ -126,7 +126,7 @@ k_accumulate(real *__restrict__ acc, const real *__restrict__ t, int len) {
 }
 
 __global__ void __launch_bounds__(SCSAMD_BLOCK)
-k_gather(const real *__restrict__ src, const int *__restrict__ map, real *__restrict__ dst, long long len) {
+k_gather(const real *__restrict__ src, const eoff *__restrict__ map, real *__restrict__ dst, long long len) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < len) dst[k] = src[map[k]];
 }
@@ -140,21 +140,27 @@ inline int grid_for(long long items) { return std::max(1, ceil_div(items, SCSAMD
 // duplicates in storage order, exactly what the host loop produces.
 constexpr int TR_SHORT = 32;      // rows up to this many entries: one lane sorts the row (insertion sort)
 constexpr int TR_LONG_MAX = 4096; // longer rows: one workgroup, bitonic sort in LDS; beyond this the host builds the pattern
-__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_count(const int *__restrict__ ci, long long nnz, int *cnt) {
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < nnz) atomicAdd(&cnt[ci[q] + 1], 1);
+__device__ __forceinline__ eoff tr_atomic_inc(eoff *p) { // entry positions are non-negative: the unsigned add is the signed one
+  if (sizeof(eoff) == 8) return (eoff)atomicAdd(reinterpret_cast<unsigned long long *>(p), 1ull);
+  return (eoff)atomicAdd(reinterpret_cast<unsigned int *>(p), 1u);
 }
-__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_scatter(const int *__restrict__ ci, long long nnz, int *nxt, int *rpos) {
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_count(const int *__restrict__ ci, long long nnz, eoff *cnt) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < nnz) rpos[atomicAdd(&nxt[ci[q]], 1)] = (int)q;
+  if (q < nnz) tr_atomic_inc(&cnt[ci[q] + 1]);
 }
-__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_short(const int *__restrict__ rp, int rows, int *rpos) {
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_scatter(const int *__restrict__ ci, long long nnz, eoff *nxt, eoff *rpos) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nnz) rpos[tr_atomic_inc(&nxt[ci[q]])] = (eoff)q;
+}
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_short(const eoff *__restrict__ rp, int rows, eoff *rpos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
-  const int a = rp[i], len = rp[i + 1] - a;
-  if (len < 2 || len > TR_SHORT) return;
+  const eoff a = rp[i];
+  const eoff len_all = rp[i + 1] - a;
+  if (len_all < 2 || len_all > TR_SHORT) return;
+  const int len = (int)len_all;
   for (int u = 1; u < len; ++u) {
-    const int v = rpos[a + u];
+    const eoff v = rpos[a + u];
     int w = u - 1;
     while (w >= 0 && rpos[a + w] > v) {
       rpos[a + w + 1] = rpos[a + w];
@@ -163,12 +169,15 @@ __global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_short(const int *__res
     rpos[a + w + 1] = v;
   }
 }
-__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_long(const int *__restrict__ rp, const int *__restrict__ rows_long, int *rpos) {
-  __shared__ int key[TR_LONG_MAX];
-  const int i = rows_long[blockIdx.x], a = rp[i], len = rp[i + 1] - a, tid = threadIdx.x;
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_long(const eoff *__restrict__ rp, const int *__restrict__ rows_long, eoff *rpos) {
+  __shared__ eoff key[TR_LONG_MAX];
+  const int i = rows_long[blockIdx.x], tid = threadIdx.x;
+  const eoff a = rp[i];
+  const int len = (int)(rp[i + 1] - a); // <= TR_LONG_MAX (checked on the host)
   int P2 = 64;
   while (P2 < len) P2 <<= 1;
-  for (int t = tid; t < P2; t += SCSAMD_BLOCK) key[t] = t < len ? rpos[a + t] : 0x7fffffff;
+  const eoff pad = sizeof(eoff) == 8 ? (eoff)0x7fffffffffffffffLL : (eoff)0x7fffffff;
+  for (int t = tid; t < P2; t += SCSAMD_BLOCK) key[t] = t < len ? rpos[a + t] : pad;
   __syncthreads();
   for (int k = 2; k <= P2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -176,7 +185,7 @@ __global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_long(const int *__rest
         const int x = e ^ j;
         if (x > e) {
           const bool asc = (e & k) == 0;
-          const int va = key[e], vb = key[x];
+          const eoff va = key[e], vb = key[x];
           if ((va > vb) == asc) {
             key[e] = vb;
             key[x] = va;
@@ -188,12 +197,12 @@ __global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_sort_long(const int *__rest
   for (int t = tid; t < len; t += SCSAMD_BLOCK) rpos[a + t] = key[t];
 }
 // the column of every CSC entry, then the CSR column indices through the position map
-__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_expand_cols(const int *__restrict__ cp, int cols, int *colidx) {
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_tr_expand_cols(const eoff *__restrict__ cp, int cols, int *colidx) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
-  for (int q = cp[j]; q < cp[j + 1]; ++q) colidx[q] = j;
+  for (eoff q = cp[j]; q < cp[j + 1]; ++q) colidx[q] = j;
 }
-__global__ void __launch_bounds__(SCSAMD_BLOCK) k_gather_int(const int *__restrict__ src, const int *__restrict__ map, int *__restrict__ dst, long long len) {
+__global__ void __launch_bounds__(SCSAMD_BLOCK) k_gather_int(const int *__restrict__ src, const eoff *__restrict__ map, int *__restrict__ dst, long long len) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < len) dst[k] = src[map[k]];
 }
@@ -216,7 +225,8 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
   CsrPattern local;
   CsrPattern &R = csr_cache ? *csr_cache : local;
   // ---- the CSC arrays go up first: the pattern transpose below runs on them
-  DevBuf<int> cp((size_t)n + 1), ci((size_t)nnz), rp((size_t)m + 1), rj((size_t)nnz), rpos((size_t)nnz);
+  DevBuf<eoff> cp((size_t)n + 1), rp((size_t)m + 1), rpos((size_t)nnz);
+  DevBuf<int> ci((size_t)nnz), rj((size_t)nnz);
   DevBuf<real> cx((size_t)nnz), rx((size_t)nnz), Dt((size_t)m), Et((size_t)n), D((size_t)m), E((size_t)n);
   cp.upload(A.p.data(), (size_t)n + 1, st);
   ci.upload(A.i.data(), (size_t)nnz, st);
@@ -230,10 +240,10 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
     H.pos.resize((size_t)nnz);
     for (long long q = 0; q < nnz; ++q) H.rp[(size_t)A.i[q] + 1]++;
     for (int i = 0; i < m; ++i) H.rp[i + 1] += H.rp[i];
-    std::vector<int> nxt(H.rp.begin(), H.rp.end() - 1);
+    std::vector<eoff> nxt(H.rp.begin(), H.rp.end() - 1);
     for (int j = 0; j < n; ++j)
-      for (int q = A.p[j]; q < A.p[j + 1]; ++q) {
-        const int t = nxt[A.i[q]]++;
+      for (eoff q = A.p[j]; q < A.p[j + 1]; ++q) {
+        const eoff t = nxt[A.i[q]]++;
         H.rj[t] = j;
         H.pos[t] = q;
       }
@@ -246,19 +256,20 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
     R.rp.assign((size_t)m + 1, 0);
     rp.download(R.rp.data(), (size_t)m + 1, st);
     HIP_CHECK(hipStreamSynchronize(st));
-    int maxlen = 0;
+    eoff maxlen = 0;
     std::vector<int> long_rows;
     for (int i = 0; i < m; ++i) {
-      const int len = R.rp[i + 1];
+      const eoff len = R.rp[i + 1];
       if (len > TR_SHORT) long_rows.push_back(i);
-      maxlen = std::max(maxlen, len);
+      maxlen = std::max<eoff>(maxlen, len);
       R.rp[i + 1] += R.rp[i];
     }
     if (maxlen <= TR_LONG_MAX) {
       tr_on_dev = true;
       rp.upload(R.rp.data(), (size_t)m + 1, st);
-      DevBuf<int> nxt((size_t)m + 1), colidx((size_t)nnz), dlong(long_rows.size() ? long_rows.size() : 1);
-      HIP_CHECK(hipMemcpyAsync(nxt.p, rp.p, (size_t)m * sizeof(int), hipMemcpyDeviceToDevice, st));
+      DevBuf<eoff> nxt((size_t)m + 1);
+      DevBuf<int> colidx((size_t)nnz), dlong(long_rows.size() ? long_rows.size() : 1);
+      HIP_CHECK(hipMemcpyAsync(nxt.p, rp.p, (size_t)m * sizeof(eoff), hipMemcpyDeviceToDevice, st));
       hipLaunchKernelGGL(k_tr_scatter, dim3(gq), Bq, 0, st, ci.p, nnz, nxt.p, rpos.p);
       hipLaunchKernelGGL(k_tr_sort_short, dim3(grid_for(m)), Bq, 0, st, rp.p, m, rpos.p);
       if (!long_rows.empty()) {
@@ -274,7 +285,8 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
       if (tr_mode == 2) { // verify against the host loop
         CsrPattern H;
         host_transpose_pattern(H);
-        std::vector<int> gj((size_t)nnz), gp((size_t)nnz);
+        std::vector<int> gj((size_t)nnz);
+        std::vector<eoff> gp((size_t)nnz);
         rj.download(gj.data(), (size_t)nnz, st);
         rpos.download(gp.data(), (size_t)nnz, st);
         HIP_CHECK(hipStreamSynchronize(st));
@@ -291,23 +303,24 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
   }
   R.built_on_device = tr_on_dev;
   // ---- full symmetric P pattern with the position of each upper entry
-  std::vector<int> fp, fj, fsrc, upos;
+  std::vector<eoff> fp, fsrc, upos;
+  std::vector<int> fj;
   if (P) {
     fp.assign((size_t)n + 1, 0);
     for (int j = 0; j < n; ++j)
-      for (int q = P->p[j]; q < P->p[j + 1]; ++q) {
+      for (eoff q = P->p[j]; q < P->p[j + 1]; ++q) {
         fp[(size_t)j + 1]++;
         if (P->i[q] != j) fp[(size_t)P->i[q] + 1]++;
       }
     for (int i = 0; i < n; ++i) fp[i + 1] += fp[i];
-    std::vector<int> nxt(fp.begin(), fp.end() - 1);
+    std::vector<eoff> nxt(fp.begin(), fp.end() - 1);
     fj.resize((size_t)fp[n]);
     fsrc.resize((size_t)fp[n]);
     upos.resize((size_t)P->p[n]);
     for (int j = 0; j < n; ++j)
-      for (int q = P->p[j]; q < P->p[j + 1]; ++q) {
+      for (eoff q = P->p[j]; q < P->p[j + 1]; ++q) {
         const int i = P->i[q];
-        int t = nxt[j]++; // row j, column i
+        eoff t = nxt[j]++; // row j, column i
         fj[t] = i;
         fsrc[t] = q;
         upos[q] = t;
@@ -339,7 +352,8 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
   sc.D.assign((size_t)m, (real)1);
   D.upload(sc.D.data(), (size_t)m, st);
   E.upload(sc.E.data(), (size_t)n, st);
-  DevBuf<int> pp, pj, psrc, pupos, boff, blen, soff, slen;
+  DevBuf<eoff> pp, psrc, pupos;
+  DevBuf<int> pj, boff, blen, soff, slen;
   DevBuf<real> px, pux;
   long long pnnz_full = 0, pnnz_up = 0;
   if (P) {
@@ -387,7 +401,7 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
       hipLaunchKernelGGL(k_cone_max_small, dim3(grid_for((long long)small_off.size())), B, 0, st, soff.p, slen.p,
                          (int)small_off.size(), Dt.p);
     hipLaunchKernelGGL(k_inv_sqrt_scale, dim3(gm), B, 0, st, Dt.p, m);
-    hipLaunchKernelGGL(k_col_stat<0>, dim3(gn), B, 0, st, cp.p, cx.p, P ? pp.p : (const int *)nullptr,
+    hipLaunchKernelGGL(k_col_stat<0>, dim3(gn), B, 0, st, cp.p, cx.p, P ? (const eoff *)pp.p : (const eoff *)nullptr,
                        P ? px.p : (const real *)nullptr, n, Et.p);
     rescale_all();
   }
@@ -413,7 +427,7 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
     }
     Dt.upload(hDt.data(), (size_t)m, st);
     hipLaunchKernelGGL(k_inv_sqrt_scale, dim3(gm), B, 0, st, Dt.p, m);
-    hipLaunchKernelGGL(k_col_stat<1>, dim3(gn), B, 0, st, cp.p, cx.p, P ? pp.p : (const int *)nullptr,
+    hipLaunchKernelGGL(k_col_stat<1>, dim3(gn), B, 0, st, cp.p, cx.p, P ? (const eoff *)pp.p : (const eoff *)nullptr,
                        P ? px.p : (const real *)nullptr, n, Et.p);
     rescale_all();
     HIP_CHECK(hipStreamSynchronize(st)); // hDt is reused / freed

@@ -466,6 +466,11 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg3_update(real *x, real *r, r
   }
 }
 
+// test hook of the DLONG build (SCS_AMD_TEST_OFFSET_BIAS): entry positions += bias (see CsrDev::bias)
+__global__ __launch_bounds__(SCSAMD_BLOCK) void k_add_bias(eoff *a, long long len, eoff bias) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) a[i] += bias;
+}
+
 // p'Gp partials (sharded solve: the dot product can only be taken after the all-reduce that completes Gp)
 __global__ __launch_bounds__(SCSAMD_BLOCK) void k_dot_partial(const real *__restrict__ a, const real *__restrict__ b, int n,
                                                               real *part, const int *skip) {
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_precond(CsrView At, const real
                                                           const real *__restrict__ pdiag, real *M) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < At.rows; i += gridDim.x * blockDim.x) {
     real acc = rx[i];
-    for (int k = At.ptr[i]; k < At.ptr[i + 1]; ++k) {
+    for (eoff k = At.ptr[i]; k < At.ptr[i + 1]; ++k) {
       const real a = At.val[k];
       acc += a * a / ry[At.idx[k]];
     }
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void k_cg2_a(CsrView A, const real *_
   real psum = 0;
   for (int i = tid; i < cnt_pgp; i += SCSAMD_BLOCK) psum += part_pgp[i];
   if ((int)blockIdx.x < A.nblk) {
-    const int touch = A.rowblk[blockIdx.x + 1] ^ A.blkptr[blockIdx.x + 1];
+    const int touch = A.rowblk[blockIdx.x + 1] ^ (int)A.blkptr[blockIdx.x + 1];
     asm volatile("" ::"v"(touch));
   }
   if (done) return;
@@ -694,7 +699,7 @@ constexpr int FUSED_THREADS = 1024;
 
 __device__ __forceinline__ real fused_row(const CsrView &A, const real *x, int r) {
   real acc = 0;
-  for (int k = A.ptr[r]; k < A.ptr[r + 1]; ++k) acc += A.val[k] * x[A.idx[k]];
+  for (eoff k = A.ptr[r]; k < A.ptr[r + 1]; ++k) acc += A.val[k] * x[A.idx[k]];
   return acc;
 }
 // y = (R_x + P + A' R_y^-1 A) x ; returns nothing, caller syncs
@@ -704,7 +709,7 @@ __device__ void fused_matvec(const CsrView &A, const CsrView &At, const CsrView 
   __syncthreads();
   for (int r = threadIdx.x; r < At.rows; r += FUSED_THREADS) {
     real acc = P ? fused_row(*P, x, r) : (real)0;
-    for (int k = At.ptr[r]; k < At.ptr[r + 1]; ++k) acc += At.val[k] * tmp[At.idx[k]];
+    for (eoff k = At.ptr[r]; k < At.ptr[r + 1]; ++k) acc += At.val[k] * tmp[At.idx[k]];
     y[r] = acc + rx[r] * x[r];
   }
   __syncthreads();
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_linsys_fused(CsrView A, CsrVi
   __syncthreads();
   for (int j = tid; j < n; j += FUSED_THREADS) {
     real acc = b[j];
-    for (int k = At.ptr[j]; k < At.ptr[j + 1]; ++k) acc += At.val[k] * tmp[At.idx[k]];
+    for (eoff k = At.ptr[j]; k < At.ptr[j + 1]; ++k) acc += At.val[k] * tmp[At.idx[k]];
     b[j] = acc;
   }
   __syncthreads();
@@ -905,8 +910,8 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
 
 // counting-sort transpose CSC(A) -> CSR(A) on the host (what private.c:7-46
 // does); columns within each output row come out sorted.
-static void host_transpose(int rows_out, int cols_out, const int *Ap, const int *Ai, const real *Ax,
-                           std::vector<int> &Cp, std::vector<int> &Ci, std::vector<real> &Cx) {
+static void host_transpose(int rows_out, int cols_out, const eoff *Ap, const int *Ai, const real *Ax,
+                           std::vector<eoff> &Cp, std::vector<int> &Ci, std::vector<real> &Cx) {
   // input: CSC with cols_out columns, rows_out rows.  output: CSR with rows_out rows.
   const long long nnz = Ap[cols_out];
   Cp.assign((size_t)rows_out + 1, 0);
@@ -914,10 +919,10 @@ static void host_transpose(int rows_out, int cols_out, const int *Ap, const int 
   Cx.resize((size_t)nnz);
   for (long long k = 0; k < nnz; ++k) Cp[(size_t)Ai[k] + 1]++;
   for (int i = 0; i < rows_out; ++i) Cp[i + 1] += Cp[i];
-  std::vector<int> nxt(Cp.begin(), Cp.end() - 1);
+  std::vector<eoff> nxt(Cp.begin(), Cp.end() - 1);
   for (int j = 0; j < cols_out; ++j)
-    for (int k = Ap[j]; k < Ap[j + 1]; ++k) {
-      const int q = nxt[Ai[k]]++;
+    for (eoff k = Ap[j]; k < Ap[j + 1]; ++k) {
+      const eoff q = nxt[Ai[k]]++;
       Ci[q] = j;
       Cx[q] = Ax[k];
     }
@@ -966,7 +971,8 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
       if (dbg_t) fprintf(stderr, "[scs_amd linsys init] A  gathers: %.3f distinct lines per entry -> %s stream; layout built on the %s\n", A.wave->lines_per_entry, A.wave->pipelined ? "pipelined" : "plain", A.wave->built_on_device ? "device" : "host");
     }
   } else {
-    std::vector<int> Cp_own, Ci_own;
+    std::vector<eoff> Cp_own;
+    std::vector<int> Ci_own;
     std::vector<real> Cx;
     const bool have_pat = pat && !pat->empty() && !pat->rj.empty() && !pat->pos.empty();
     if (have_pat) { // values follow the cached pattern: a gather, not a sort
@@ -976,7 +982,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
     } else {
       host_transpose(m, n, A_csc->p, A_csc->i, A_csc->x, Cp_own, Ci_own, Cx);
     }
-    const std::vector<int> &Cp = have_pat ? pat->rp : Cp_own;
+    const std::vector<eoff> &Cp = have_pat ? pat->rp : Cp_own;
     const std::vector<int> &Ci = have_pat ? pat->rj : Ci_own;
     phase("transpose");
     A.upload(m, n, Cp.data(), Ci.data(), Cx.data(), stream);
@@ -991,24 +997,26 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
   has_P = P_csc != nullptr;
   if (has_P) {
     // expand the stored upper triangle to the full symmetric matrix (CSR == CSC)
-    const int *Pp_ = P_csc->p, *Pi = P_csc->i;
+    const eoff *Pp_ = P_csc->p;
+    const int *Pi = P_csc->i;
     const real *Px = P_csc->x;
-    std::vector<int> cnt((size_t)n + 1, 0);
+    std::vector<eoff> cnt((size_t)n + 1, 0);
     std::vector<real> pd((size_t)n, 0);
     for (int j = 0; j < n; ++j)
-      for (int k = Pp_[j]; k < Pp_[j + 1]; ++k) {
+      for (eoff k = Pp_[j]; k < Pp_[j + 1]; ++k) {
         const int i = Pi[k];
         cnt[(size_t)j + 1]++;
         if (i != j) cnt[(size_t)i + 1]++;
         else pd[j] += Px[k]; // private.c:69-75
       }
     for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
-    std::vector<int> nxt(cnt.begin(), cnt.end() - 1), Fi((size_t)cnt[n]);
+    std::vector<eoff> nxt(cnt.begin(), cnt.end() - 1);
+    std::vector<int> Fi((size_t)cnt[n]);
     std::vector<real> Fx((size_t)cnt[n]);
     for (int j = 0; j < n; ++j)
-      for (int k = Pp_[j]; k < Pp_[j + 1]; ++k) {
+      for (eoff k = Pp_[j]; k < Pp_[j + 1]; ++k) {
         const int i = Pi[k];
-        int q = nxt[j]++; // row j, column i
+        eoff q = nxt[j]++; // row j, column i
         Fi[q] = i;
         Fx[q] = Px[k];
         if (i != j) {
@@ -1073,6 +1081,28 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
   Gp.alloc(n);
   z.alloc(n);
   tmp.alloc(m);
+  // 64-bit entry positions exercised without a 26 GB matrix (DLONG build only, tests/test_dlong_gpu.py): every stored entry position
+  // (row pointers, row-block first entries, unit entry ranges) gets +bias and the arrays they index are handed to the kernels shifted by
+  // -bias -- a kernel that narrows a position to 32 bits anywhere between the table and the load reads the wrong entry.  bias must be a
+  // multiple of 4 (the wave kernels load 16 bytes of 4-byte words at a time).
+  if (sizeof(eoff) == 8)
+    if (const char *e = getenv("SCS_AMD_TEST_OFFSET_BIAS")) {
+      const long long bias = atoll(e) & ~3LL;
+      auto shift = [&](CsrDev &M) {
+        if (M.rows <= 0 || bias == 0) return;
+        hipLaunchKernelGGL(k_add_bias, dim3(vec_grid(M.rows + 1)), dim3(SCSAMD_BLOCK), 0, stream, M.ptr.p, (long long)M.rows + 1, (eoff)bias);
+        hipLaunchKernelGGL(k_add_bias, dim3(vec_grid(M.nblk + 1)), dim3(SCSAMD_BLOCK), 0, stream, M.blkptr.p, (long long)M.nblk + 1, (eoff)bias);
+        M.bias = bias;
+        if (M.wave && M.wave->built) {
+          hipLaunchKernelGGL(k_add_bias, dim3(vec_grid(2LL * M.wave->nunit)), dim3(SCSAMD_BLOCK), 0, stream, M.wave->useg.p, 2LL * M.wave->nunit, (eoff)bias);
+          M.wave->bias = bias;
+        }
+      };
+      shift(A);
+      shift(At);
+      if (has_P) shift(P);
+      HIP_CHECK(hipGetLastError());
+    }
   partA.alloc(PART_CAP);
   partB.alloc(PART_CAP);
   if (use_cg3) {

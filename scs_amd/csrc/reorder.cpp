@@ -14,15 +14,15 @@ double now_s() {
 
 // transpose of a pattern: (ptr, idx) with `rows` rows over `cols` columns -> (tptr, tidx) with `cols` rows (counting sort,
 // like linsys/cpu/indirect/private.c:7-46 without the values)
-void transpose_pattern(const int *ptr, const int *idx, int rows, int cols, std::vector<int> &tptr, std::vector<int> &tidx) {
+void transpose_pattern(const eoff *ptr, const int *idx, int rows, int cols, std::vector<eoff> &tptr, std::vector<int> &tidx) {
   const size_t nnz = (size_t)ptr[rows];
   tptr.assign((size_t)cols + 1, 0);
   for (size_t k = 0; k < nnz; ++k) tptr[(size_t)idx[k] + 1]++;
   for (int c = 0; c < cols; ++c) tptr[c + 1] += tptr[c];
   tidx.resize(nnz);
-  std::vector<int> fill(tptr.begin(), tptr.end() - 1);
+  std::vector<eoff> fill(tptr.begin(), tptr.end() - 1);
   for (int r = 0; r < rows; ++r)
-    for (int k = ptr[r]; k < ptr[r + 1]; ++k) tidx[(size_t)fill[idx[k]]++] = r;
+    for (eoff k = ptr[r]; k < ptr[r + 1]; ++k) tidx[(size_t)fill[idx[k]]++] = r;
 }
 
 // stable argsort of keys; entries with key < 0 ("no key") keep their relative order behind the keyed ones
@@ -39,7 +39,7 @@ std::vector<int> order_by_key(const std::vector<double> &key) {
 
 } // namespace
 
-double lines_per_entry(const int *ptr, const int *idx, int rows, int cols, size_t elem_bytes) {
+double lines_per_entry(const eoff *ptr, const int *idx, int rows, int cols, size_t elem_bytes) {
   const long long nnz = ptr[rows];
   if (nnz <= 0) return 1.0;
   const int lshift = elem_bytes == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
@@ -54,7 +54,7 @@ double lines_per_entry(const int *ptr, const int *idx, int rows, int cols, size_
       acc = 0;
       unit_rows = 0;
     }
-    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+    for (eoff k = ptr[r]; k < ptr[r + 1]; ++k) {
       int &st = stamp[(size_t)idx[k] >> lshift];
       if (st != unit) {
         st = unit;
@@ -90,17 +90,20 @@ void place_free_rows(const std::vector<double> &rkey, int z, int lp, int m, std:
 
 void measure(const HostCsc &A, Candidate &c) {
   const int m = A.m, n = A.n;
-  const int *cp = A.p.data(), *ci = A.i.data();
+  const eoff *cp = A.p.data();
+  const int *ci = A.i.data();
   std::vector<int> row_old2new((size_t)m);
   for (int i = 0; i < m; ++i) row_old2new[c.row_new2old[i]] = i;
-  std::vector<int> np((size_t)n + 1, 0), ni((size_t)cp[n]);
+  std::vector<eoff> np((size_t)n + 1, 0);
+  std::vector<int> ni((size_t)cp[n]);
   for (int j = 0; j < n; ++j) np[j + 1] = np[j] + (cp[c.col_new2old[j] + 1] - cp[c.col_new2old[j]]);
   for (int j = 0; j < n; ++j) {
-    int o = np[j];
+    eoff o = np[j];
     const int jo = c.col_new2old[j];
-    for (int q = cp[jo]; q < cp[jo + 1]; ++q) ni[(size_t)o++] = row_old2new[ci[q]];
+    for (eoff q = cp[jo]; q < cp[jo + 1]; ++q) ni[(size_t)o++] = row_old2new[ci[q]];
   }
-  std::vector<int> tp, ti;
+  std::vector<eoff> tp;
+  std::vector<int> ti;
   transpose_pattern(np.data(), ni.data(), n, m, tp, ti);
   c.after[1] = lines_per_entry(np.data(), ni.data(), n, m, sizeof(real));
   c.after[0] = lines_per_entry(tp.data(), ti.data(), m, n, sizeof(real));
@@ -129,7 +132,8 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   }
   if (m < 2 || n < 2) return;
   const int z = (int)k->z, lp = (int)k->l, fixed0 = z + lp; // rows [0, z) and [z, z + l) may move inside their range; the rest are anchors
-  const int *cp = A.p.data(), *ci = A.i.data();
+  const eoff *cp = A.p.data();
+  const int *ci = A.i.data();
   // ---- one pass: anchors per column and how tightly they sit
   std::vector<double> ckey((size_t)n, -1.0);
   long long anchored = 0, spread_cols = 0, unkeyed = 0;
@@ -138,7 +142,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   for (int j = 0; j < n; ++j) {
     double s = 0;
     int cnt = 0, lo = m, hi = -1;
-    for (int q = cp[j]; q < cp[j + 1]; ++q) {
+    for (eoff q = cp[j]; q < cp[j + 1]; ++q) {
       const int i = ci[q];
       if (i >= fixed0) {
         s += i;
@@ -169,7 +173,8 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
       return;
     }
   }
-  std::vector<int> rptr, rcol; // CSR pattern of A (rows -> columns)
+  std::vector<eoff> rptr; // CSR pattern of A (rows -> columns)
+  std::vector<int> rcol;
   transpose_pattern(cp, ci, n, m, rptr, rcol);
   R.before[1] = lines_per_entry(cp, ci, n, m, sizeof(real));                    // A' product: rows = columns of A, gathers y
   R.before[0] = lines_per_entry(rptr.data(), rcol.data(), m, n, sizeof(real)); // A product: rows of A, gathers x
@@ -194,7 +199,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     for (int i = 0; i < fixed0; ++i) {
       double s = 0;
       int cnt = 0;
-      for (int q = rptr[i]; q < rptr[i + 1]; ++q) {
+      for (eoff q = rptr[i]; q < rptr[i + 1]; ++q) {
         s += col_old2new[rcol[q]];
         ++cnt;
       }
@@ -223,7 +228,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
         const int v = q[head++];
         last = v;
         if (v < n) {
-          for (int e = cp[v]; e < cp[v + 1]; ++e) {
+          for (eoff e = cp[v]; e < cp[v + 1]; ++e) {
             const int u = n + ci[e];
             if (mark[u] != tag) {
               mark[u] = tag;
@@ -232,7 +237,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
           }
         } else {
           const int i = v - n;
-          for (int e = rptr[i]; e < rptr[i + 1]; ++e) {
+          for (eoff e = rptr[i]; e < rptr[i + 1]; ++e) {
             const int u = rcol[e];
             if (mark[u] != tag) {
               mark[u] = tag;
@@ -301,9 +306,9 @@ void apply_reorder(HostCsc &A, const Reorder &R) {
   for (int j = 0; j < n; ++j) {
     const int jo = R.col_new2old[j];
     col.clear();
-    for (int q = A.p[jo]; q < A.p[jo + 1]; ++q) col.emplace_back(row_old2new[A.i[q]], A.x[q]);
+    for (eoff q = A.p[jo]; q < A.p[jo + 1]; ++q) col.emplace_back(row_old2new[A.i[q]], A.x[q]);
     std::stable_sort(col.begin(), col.end(), [](const std::pair<int, real> &a, const std::pair<int, real> &b) { return a.first < b.first; });
-    int o = B.p[j];
+    eoff o = B.p[j];
     for (const auto &e : col) {
       B.i[(size_t)o] = e.first;
       B.x[(size_t)o] = e.second;

@@ -38,6 +38,6 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R);
 // A <- A[row_new2old, col_new2old], row indices sorted inside every column
 void apply_reorder(HostCsc &A, const Reorder &R);
 // distinct 128-byte lines of the gathered vector per entry, over units of consecutive rows of ~ nnz / 2048 entries
-double lines_per_entry(const int *ptr, const int *idx, int rows, int cols, size_t elem_bytes);
+double lines_per_entry(const eoff *ptr, const int *idx, int rows, int cols, size_t elem_bytes);
 
 } // namespace scsamd

@@ -10,14 +10,16 @@ typedef scs_float real;
 // widens the boundary structs).  Without DLONG it aliases the caller's arrays, with DLONG CscArg narrows a copy.
 struct CscView {
   real *x;
-  int *i, *p;
+  int *i;  // row indices: 32-bit
+  eoff *p; // column pointers: entry positions
   int m, n;
 };
 
 // owned host CSC copy (deep copy of the user's matrix; equilibrated in place)
 struct HostCsc {
   int m = 0, n = 0;
-  std::vector<int> p, i;
+  std::vector<eoff> p;
+  std::vector<int> i;
   std::vector<real> x;
   void copy_from(const ScsMatrix *M) {
     m = (int)M->m;
@@ -25,7 +27,7 @@ struct HostCsc {
     const size_t nnz = (size_t)M->p[M->n];
     p.resize((size_t)n + 1);
     i.resize(nnz);
-    for (size_t j = 0; j <= (size_t)n; ++j) p[j] = (int)M->p[j];
+    for (size_t j = 0; j <= (size_t)n; ++j) p[j] = (eoff)M->p[j];
     for (size_t j = 0; j < nnz; ++j) i[j] = (int)M->i[j];
     x.assign(M->x, M->x + nnz);
   }
@@ -41,7 +43,7 @@ struct CscArg {
     if (!M) return;
     present = true;
     if (sizeof(scs_int) == sizeof(int)) {
-      v = CscView{M->x, reinterpret_cast<int *>(M->i), reinterpret_cast<int *>(M->p), (int)M->m, (int)M->n};
+      v = CscView{M->x, reinterpret_cast<int *>(M->i), reinterpret_cast<eoff *>(M->p), (int)M->m, (int)M->n};
     } else {
       own.copy_from(M);
       v = own.view();
@@ -50,11 +52,12 @@ struct CscArg {
   const CscView *ptr() const { return present ? &v : nullptr; }
 };
 
-// every size and index of a caller's matrix must fit the device's 32-bit indexing (only -DDLONG can violate it)
+// every size and index of a caller's matrix must fit the device's indexing: m, n and every row index 32-bit; the number of nonzeros
+// 32-bit too unless entry positions are 64-bit (eoff: the DLONG build)
 inline bool fits_int32(const ScsMatrix *M) {
   if (!M || !M->p) return true; // missing arrays are validate_csc's business
   if ((long long)M->m > 2147483647LL || (long long)M->n > 2147483647LL || M->n < 0) return false;
-  return (long long)M->p[M->n] < 2147483647LL;
+  return sizeof(eoff) == 8 || (long long)M->p[M->n] < 2147483647LL;
 }
 
 // reference include/scs_work.h:24-29 (ScsScaling)
@@ -69,20 +72,24 @@ struct Scaling {
 // CSR(A) in rp / rj / rx -- so that LinSys::init adopts them instead of gathering the values on the host and uploading 2 x 12 B / nnz
 // again.  With `dev.valid` the host copies rj / pos may be empty (the transpose was built on the device): they are fetched on demand.
 struct DevMatrices {
-  DevBuf<int> cp, ci, rp, rj, rpos;
+  DevBuf<eoff> cp, rp, rpos;
+  DevBuf<int> ci, rj;
   DevBuf<real> cx, rx;
   bool valid = false;
 };
 struct CsrPattern {
-  std::vector<int> rp, rj, pos;
+  std::vector<eoff> rp, pos; // row pointers; CSC position of every CSR entry
+  std::vector<int> rj;
   DevMatrices dev;
   bool built_on_device = false; // the transpose (rj, pos) was formed on the device: the host copies are empty
   bool empty() const { return rp.empty(); }
   void clear() {
-    rp = std::vector<int>();
+    rp = std::vector<eoff>();
     rj = std::vector<int>();
-    pos = std::vector<int>();
-    for (DevBuf<int> *b : {&dev.cp, &dev.ci, &dev.rp, &dev.rj, &dev.rpos}) b->release();
+    pos = std::vector<eoff>();
+    for (DevBuf<eoff> *b : {&dev.cp, &dev.rp, &dev.rpos}) b->release();
+    dev.ci.release();
+    dev.rj.release();
     dev.cx.release();
     dev.rx.release();
     dev.valid = false;

@@ -33,11 +33,11 @@ constexpr int SPMV_UNROLL = NNZ_PER_BLOCK / SCSAMD_BLOCK; // 8
 
 struct CsrView {
   int rows, cols, nblk;
-  const int *ptr;    // rows + 1
+  const eoff *ptr;   // rows + 1 : entry positions (64-bit in the DLONG build)
   const int *idx;    // nnz
   const real *val;   // nnz
   const int *rowblk; // nblk + 1 : first row of each row-block
-  const int *blkptr; // nblk + 1 : ptr[rowblk[b]] (first entry of each row-block: saves a dependent read)
+  const eoff *blkptr; // nblk + 1 : ptr[rowblk[b]] (first entry of each row-block: saves a dependent read)
 };
 
 // Epilogues (what happens to the row sum `acc`):
@@ -117,7 +117,8 @@ __device__ __forceinline__ void csr_stream_blocks(const CsrView &A, const real *
                                                   real *red, int b0, int nb, real &dot) {
   const int tid = threadIdx.x;
   int b = b0;
-  int r0 = 0, r1 = 0, k0 = 0, k1 = 0;
+  int r0 = 0, r1 = 0;
+  eoff k0 = 0, k1 = 0;
   if (b < A.nblk) {
     r0 = A.rowblk[b];
     r1 = A.rowblk[b + 1];
@@ -125,11 +126,12 @@ __device__ __forceinline__ void csr_stream_blocks(const CsrView &A, const real *
     k1 = A.blkptr[b + 1];
   }
   while (b < A.nblk) {
-    const int cnt = k1 - k0;
+    const eoff cnt_all = k1 - k0;
+    const int cnt = cnt_all > NNZ_PER_BLOCK ? NNZ_PER_BLOCK + 1 : (int)cnt_all;
     if (cnt > NNZ_PER_BLOCK) {
       // one long row: strided partial sums, workgroup tree reduction
       real acc = 0;
-      for (int k = k0 + tid; k < k1; k += SCSAMD_BLOCK) acc += A.val[k] * x[A.idx[k]];
+      for (eoff k = k0 + tid; k < k1; k += SCSAMD_BLOCK) acc += A.val[k] * x[A.idx[k]];
       acc = block_sum(acc, red);
       if (tid == 0) {
         acc += epi_init<EPI>(e, y, r0);
@@ -152,8 +154,8 @@ __device__ __forceinline__ void csr_stream_blocks(const CsrView &A, const real *
       int a0 = 0, z0 = 0;
       real init0 = 0, d0 = 1, x0 = 0;
       if (has) {
-        a0 = A.ptr[rf] - k0;
-        z0 = A.ptr[rf + 1] - k0;
+        a0 = (int)(A.ptr[rf] - k0);
+        z0 = (int)(A.ptr[rf + 1] - k0);
         init0 = epi_init<EPI>(e, y, rf);
         if (EPI == EPI_DIV || EPI == EPI_NEGDIV || EPI == EPI_GP) d0 = e.d[rf];
         if (EPI == EPI_GP) x0 = e.xin[rf];
@@ -174,7 +176,7 @@ __device__ __forceinline__ void csr_stream_blocks(const CsrView &A, const real *
         epi_apply_pre<EPI>(y, rf, acc, d0, x0, dot);
       }
       for (int r = rf + SCSAMD_BLOCK; r < r1; r += SCSAMD_BLOCK) {
-        const int a = A.ptr[r] - k0, z = A.ptr[r + 1] - k0;
+        const int a = (int)(A.ptr[r] - k0), z = (int)(A.ptr[r + 1] - k0);
         real acc = epi_init<EPI>(e, y, r);
         for (int k = a; k < z; ++k) acc += prod[k];
         epi_apply<EPI>(e, y, r, acc, dot);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(SCSAMD_BLOCK) void csr_stream_kernel(CsrView A, con
   // the skip flag and the first row-block's table entries are requested together (csr_stream_blocks starts with them)
   const int sk = skip ? *skip : 0;
   if ((int)blockIdx.x < A.nblk) { // in flight together with the flag: csr_stream_blocks then finds the lines in L1
-    const int touch = A.rowblk[blockIdx.x + 1] ^ A.blkptr[blockIdx.x + 1];
+    const int touch = A.rowblk[blockIdx.x + 1] ^ (int)A.blkptr[blockIdx.x + 1];
     asm volatile("" ::"v"(touch));
   }
   if (sk) return;
@@ -222,9 +224,14 @@ struct CsrDev {
   CsrDev(const CsrDev &) = delete;
   int rows = 0, cols = 0, nblk = 0;
   long long nnz = 0;
-  DevBuf<int> ptr, idx, rowblk, blkptr;
+  DevBuf<eoff> ptr, blkptr;
+  DevBuf<int> idx, rowblk;
   DevBuf<real> val;
-  CsrView view() const { return CsrView{rows, cols, nblk, ptr.p, idx.p, val.p, rowblk.p, blkptr.p}; }
+  // test hook of the DLONG build (SCS_AMD_TEST_OFFSET_BIAS, apply_offset_bias): every stored entry position carries +bias and the
+  // index / value arrays are handed to the kernels shifted by -bias, so a kernel that narrows a position to 32 bits anywhere reads
+  // the wrong entry -- 64-bit entry positions exercised without a 26 GB matrix
+  long long bias = 0;
+  CsrView view() const { return CsrView{rows, cols, nblk, ptr.p, idx.p - bias, val.p - bias, rowblk.p, blkptr.p}; }
   int max_grid = SPMV_MAX_GRID; // tests shrink it (SCS_AMD_SPMV_MAX_GRID) to force grid-striding
   int grid() const { return nblk < max_grid ? (nblk > 0 ? nblk : 1) : max_grid; }
   // algorithmic bytes of one product with this matrix:
@@ -234,7 +241,7 @@ struct CsrDev {
            (long long)cols * sizeof(real) + (long long)rows * sizeof(real);
   }
   // host CSR arrays -> device, plus the row-block table
-  void upload(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval,
+  void upload(int rows_, int cols_, const eoff *hptr, const int *hidx, const real *hval,
               hipStream_t s) {
     rows = rows_;
     cols = cols_;
@@ -251,7 +258,7 @@ struct CsrDev {
   }
   // (round 5) CSR arrays that are ALREADY in HBM (left there by the device equilibration): ownership moves here, nothing is copied;
   // hptr = the host copy of the row pointers (the row-block table is cut from it)
-  void adopt(int rows_, int cols_, const int *hptr, DevBuf<int> &dptr, DevBuf<int> &didx, DevBuf<real> &dval, hipStream_t s) {
+  void adopt(int rows_, int cols_, const eoff *hptr, DevBuf<eoff> &dptr, DevBuf<int> &didx, DevBuf<real> &dval, hipStream_t s) {
     rows = rows_;
     cols = cols_;
     nnz = hptr[rows_];
@@ -260,7 +267,7 @@ struct CsrDev {
     val.take(dval);
     build_row_blocks(hptr, s);
   }
-  void build_row_blocks(const int *hptr, hipStream_t s) {
+  void build_row_blocks(const eoff *hptr, hipStream_t s) {
     if (const char *e = getenv("SCS_AMD_SPMV_MAX_GRID")) {
       int g = atoi(e);
       if (g >= 1 && g <= SPMV_MAX_GRID) max_grid = g;
@@ -283,7 +290,7 @@ struct CsrDev {
     nblk = (int)rb.size() - 1;
     rowblk.alloc(rb.size());
     rowblk.upload(rb.data(), rb.size(), s);
-    std::vector<int> bp(rb.size());
+    std::vector<eoff> bp(rb.size());
     for (size_t i = 0; i < rb.size(); ++i) bp[i] = hptr[rb[i]];
     blkptr.alloc(bp.size());
     blkptr.upload(bp.data(), bp.size(), s);

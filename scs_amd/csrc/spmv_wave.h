@@ -38,7 +38,7 @@ constexpr int WR_BUCKETS = 1024;    // column buckets per unit (ordering heurist
 struct WaveView {
   int rows, nunit, cbits, cols;
   const int *urow;     // nunit + 1 : first row of each unit
-  const int *useg;     // 2 * nunit : [first entry (4-aligned), one past the last entry] of each unit
+  const eoff *useg;    // 2 * nunit : [first entry (4-aligned), one past the last entry] of each unit (entry positions: eoff)
   const unsigned *wrd; // nnz : column | local row << cbits
   const real *val;     // nnz
 };
@@ -53,7 +53,7 @@ struct WrChunk {
   uint4 w;
   real v[4];
 };
-__device__ __forceinline__ WrChunk wr_load(const WaveView &A, int eb) {
+__device__ __forceinline__ WrChunk wr_load(const WaveView &A, eoff eb) {
   WrChunk c;
   c.w = *reinterpret_cast<const uint4 *>(A.wrd + eb);
   if (sizeof(real) == 8) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ WrChunk wr_load(const WaveView &A, int eb) {
   }
   return c;
 }
-__device__ __forceinline__ void wr_consume(const WaveView &A, const WrChunk &c, const real *__restrict__ x, real *acc, int eb, int t,
+__device__ __forceinline__ void wr_consume(const WaveView &A, const WrChunk &c, const real *__restrict__ x, real *acc, eoff eb, eoff t,
                                            unsigned cmask) {
   const unsigned w[4] = {c.w.x, c.w.y, c.w.z, c.w.w};
   real xx[4];
@@ -132,13 +132,13 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
   real dot = 0, d1 = 0, d2 = 0;
   for (int u = blockIdx.x * WR_WPB + wave; u < A.nunit; u += gridDim.x * WR_WPB) {
     const int r0 = A.urow[u], nr = A.urow[u + 1] - r0;
-    const int s = A.useg[2 * u], t = A.useg[2 * u + 1];
+    const eoff s = A.useg[2 * u], t = A.useg[2 * u + 1];
     for (int k = lane; k < nr; k += 64) acc[k] = 0;
     // a lane owns 4 consecutive entries of every 256-entry chunk (3 stream instructions per chunk instead of 8; unit
     // starts are 4-aligned)
     if (PIPE == 1) {
       WrChunk cur = wr_load(A, s + lane * 4); // (an empty unit reads the padding behind its start: harmless)
-      for (int e0 = s; e0 < t; e0 += 256) {
+      for (eoff e0 = s; e0 < t; e0 += 256) {
         const bool more = e0 + 256 < t; // uniform
         WrChunk nxt = cur;
         if (more) nxt = wr_load(A, e0 + 256 + lane * 4);
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
         cur = nxt;
       }
     } else {
-      for (int e0 = s; e0 < t; e0 += 256) {
-        const int eb = e0 + lane * 4;
+      for (eoff e0 = s; e0 < t; e0 += 256) {
+        const eoff eb = e0 + lane * 4;
         const WrChunk c = wr_load(A, eb);
         wr_consume(A, c, x, acc, eb, t, cmask);
       }
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
   for (int rd = 0; rd < nround; ++rd) {
     const int u = rd * per_round + blockIdx.x * WL_WPB + wave;
     const bool live = u < A.nunit; // wave-uniform
-    int r0 = 0, nr = 0, s = 0, t = 0;
+    int r0 = 0, nr = 0;
+    eoff s = 0, t = 0;
     if (live) {
       r0 = A.urow[u];
       nr = A.urow[u + 1] - r0;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
       t = A.useg[2 * u + 1];
     }
     for (int k = lane; k < nr; k += 64) acc[k] = 0;
-    const int nch = (t - s + 255) >> 8;
+    const int nch = (int)((t - s + 255) >> 8);
     if (lane == 0) s_nch[wave] = nch;
     __syncthreads();
     int nmax = 0;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(WL_WPB * 64) void csr_wave_lockstep_kernel(WaveView
     for (int w = 0; w < WL_WPB; ++w) nmax = s_nch[w] > nmax ? s_nch[w] : nmax;
     constexpr int bars = MODE; // barriers per chunk: 4 | 1
     auto consume = [&](const WrChunk &ch, int c) {
-      const int eb = s + c * 256 + lane * 4;
+      const eoff eb = s + c * 256 + lane * 4;
       const bool has = c < nch; // wave-uniform: a wave whose unit is shorter keeps the others company at the barriers
       const unsigned w[4] = {ch.w.x, ch.w.y, ch.w.z, ch.w.w};
       real xx[4];
@@ -247,10 +248,12 @@ struct WaveRowsDev {
   int sub_window_order = 0;    // every 256-entry chunk stored so that gather instruction i covers the i-th quarter of its column window
   int ls_wpb = 16, ls_bmode = 4; // its waves per workgroup (SCS_AMD_WR_LS_WPB = 8 | 16) and barriers per chunk (SCS_AMD_WR_LS_BARRIERS = 4 | 1)
   int wpc = 8;                 // waves per CU the layout is cut for (one unit per resident wave); SCS_AMD_WR_WPC overrides (measurements)
-  DevBuf<int> urow, useg;
+  DevBuf<int> urow;
+  DevBuf<eoff> useg;
+  long long bias = 0; // test hook of the DLONG build (CsrDev::bias): entry positions stored +bias, arrays handed over shifted by -bias
   DevBuf<unsigned> wrd;
   DevBuf<real> val;
-  WaveView view() const { return WaveView{rows, nunit, cbits, cols, urow.p, useg.p, wrd.p, val.p}; }
+  WaveView view() const { return WaveView{rows, nunit, cbits, cols, urow.p, useg.p, wrd.p - bias, val.p - bias}; }
   // every workgroup must be resident at once (8 waves per CU): a wave then walks its units one after the
   // other and all waves restart at column 0 together, which keeps the gather window of x aligned; a second
   // generation of workgroups starting at column 0 while the first is half way through thrashes L2 instead
@@ -272,7 +275,7 @@ struct WaveRowsDev {
   // From a million nonzeros on: measured us per CG iteration, this kernel vs csr_stream (fp64, 10 nonzeros per
   // column): nnz 5e5 23.5 / 23.5, 1e6 30.0 / 32.7, 1.5e6 34.8 / 38.5, 2e6 39.3 / 43.3, 4e6 61.3 / 76.5 -- no
   // barriers and no product staging pay even while the gathered vector still fits an XCD's L2
-  static bool wanted(int cols, const int *hptr, int rows) {
+  static bool wanted(int cols, const eoff *hptr, int rows) {
     if (col_bits(cols) > 26) return false; // packed word: column bits + at least 6 row bits
     if (const char *e = getenv("SCS_AMD_WAVEROWS")) return atoi(e) != 0; // tests force either path
     return (long long)hptr[rows] >= 1000000LL;
@@ -284,11 +287,12 @@ struct WaveRowsDev {
   //                                than WR_DEV_UNIT_MAX entries) and as the oracle of the device builder (SCS_AMD_WR_BUILD=verify)
   //   fill_dev   (device):         the same arrays, bit for bit, from the CSR copy already in HBM (spmv_wave_build.h): one workgroup
   //                                per unit, two in-LDS bitonic sorts on composite keys that reproduce the host's stable orders
-  std::vector<int> ur, us; // host copies of urow / useg (plan)
+  std::vector<int> ur;   // host copy of urow (plan)
+  std::vector<eoff> us;  // host copy of useg
   size_t cap = 0;
   int bshift = 0;
   long long nnz_all = 0;
-  void plan(int rows_, int cols_, const int *hptr) {
+  void plan(int rows_, int cols_, const eoff *hptr) {
     rows = rows_;
     cols = cols_;
     cbits = col_bits(cols);
@@ -349,14 +353,14 @@ struct WaveRowsDev {
     size_t q = 0; // unit starts are rounded up to 4 entries (16-byte vector loads); the gaps hold zeros
     for (int u = 0; u < nunit; ++u) {
       q = (q + 3) & ~(size_t)3;
-      us[2 * u] = (int)q;
+      us[2 * u] = (eoff)q;
       q += (size_t)(hptr[ur[u + 1]] - hptr[ur[u]]);
-      us[2 * u + 1] = (int)q;
+      us[2 * u + 1] = (eoff)q;
       accrows = std::max(accrows, ur[u + 1] - ur[u]);
     }
     accrows = (accrows + 1) & ~1;
     cap = q + 256 + 8; // the last chunk of a unit may read up to 255 entries past its end
-    if (cap >= ((size_t)1 << 31)) throw HipError("scs_amd: matrix too large for 32-bit entry offsets");
+    if (sizeof(eoff) == 4 && cap >= ((size_t)1 << 31)) throw HipError("scs_amd: matrix too large for 32-bit entry offsets (the DLONG build carries 64-bit ones)");
     bshift = std::max(0, cbits - 10);
   }
   long long max_unit_entries() const {
@@ -374,20 +378,20 @@ struct WaveRowsDev {
     if (ls_bmode < 0) ls_bmode = lines_per_entry < 0.3 ? 1 : 4;
     built = true;
   }
-  void fill_host(const int *hptr, const int *hidx, const real *hval, std::vector<unsigned> &hw, std::vector<real> &hv, long long &distinct_total) {
+  void fill_host(const eoff *hptr, const int *hidx, const real *hval, std::vector<unsigned> &hw, std::vector<real> &hv, long long &distinct_total) {
     hw.assign(cap, 0u);
     hv.assign(cap, (real)0);
     // stable counting sort of every unit by column bucket (ordering is a locality heuristic: any
     // order gives the same sums up to rounding)
     std::vector<int> cnt(WR_BUCKETS + 1);
     for (int u = 0; u < nunit; ++u) {
-      const int k0 = hptr[ur[u]], k1 = hptr[ur[u + 1]];
+      const eoff k0 = hptr[ur[u]], k1 = hptr[ur[u + 1]];
       std::fill(cnt.begin(), cnt.end(), 0);
-      for (int k = k0; k < k1; ++k) cnt[(hidx[k] >> bshift) + 1]++;
+      for (eoff k = k0; k < k1; ++k) cnt[(hidx[k] >> bshift) + 1]++;
       for (int b = 0; b < WR_BUCKETS; ++b) cnt[b + 1] += cnt[b];
       const size_t base = (size_t)us[2 * u];
       for (int rr = ur[u]; rr < ur[u + 1]; ++rr)
-        for (int k = hptr[rr]; k < hptr[rr + 1]; ++k) {
+        for (eoff k = hptr[rr]; k < hptr[rr + 1]; ++k) {
           const size_t qq = base + cnt[hidx[k] >> bshift]++;
           hw[qq] = (unsigned)hidx[k] | ((unsigned)(rr - ur[u]) << cbits);
           hv[qq] = hval[k];
@@ -427,7 +431,7 @@ struct WaveRowsDev {
       std::vector<int> stamp(((size_t)cols >> lshift) + 2, -1);
       long long distinct = 0;
       for (int u = 0; u < nunit; ++u)
-        for (int k = hptr[ur[u]]; k < hptr[ur[u + 1]]; ++k) {
+        for (eoff k = hptr[ur[u]]; k < hptr[ur[u + 1]]; ++k) {
           int &st = stamp[(size_t)hidx[k] >> lshift];
           if (st != u) {
             st = u;
@@ -446,7 +450,7 @@ struct WaveRowsDev {
     useg.upload(us.data(), us.size(), st);
   }
   // rounds 2-4's entry point: everything on the host, then uploaded
-  void build(int rows_, int cols_, const int *hptr, const int *hidx, const real *hval, hipStream_t st) {
+  void build(int rows_, int cols_, const eoff *hptr, const int *hidx, const real *hval, hipStream_t st) {
     plan(rows_, cols_, hptr);
     std::vector<unsigned> hw;
     std::vector<real> hv;

@@ -61,9 +61,9 @@ __device__ __forceinline__ int wb_deal(int r, int len) {
 }
 
 template <bool SUBWIN>
-__global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const int *__restrict__ ptr, const int *__restrict__ idx,
+__global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const eoff *__restrict__ ptr, const int *__restrict__ idx,
                                                             const real *__restrict__ val, const int *__restrict__ urow,
-                                                            const int *__restrict__ useg, unsigned *wrd, real *vout, int cbits,
+                                                            const eoff *__restrict__ useg, unsigned *wrd, real *vout, int cbits,
                                                             int bshift, int lshift, int bm_words, unsigned long long *distinct) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wb_smem[];
   unsigned long long *key64 = reinterpret_cast<unsigned long long *>(wb_smem);
@@ -73,13 +73,14 @@ __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const int *__restric
   __shared__ unsigned red[WB_THREADS / 64];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int r0 = urow[u], r1 = urow[u + 1];
-  const int k0 = ptr[r0], k1 = ptr[r1], len = k1 - k0, base = useg[2 * u];
+  const eoff k0 = ptr[r0], k1 = ptr[r1], base = useg[2 * u];
+  const int len = (int)(k1 - k0); // <= WR_DEV_UNIT_MAX (checked on the host)
   if (len <= 0) return; // uniform
   int P2 = 256;
   while (P2 < len) P2 <<= 1;
   for (int w = tid; w < bm_words; w += WB_THREADS) bm[w] = 0;
   for (int rr = r0 + tid; rr < r1; rr += WB_THREADS)
-    for (int k = ptr[rr]; k < ptr[rr + 1]; ++k) rowl[k - k0] = (unsigned short)(rr - r0);
+    for (eoff k = ptr[rr]; k < ptr[rr + 1]; ++k) rowl[k - k0] = (unsigned short)(rr - r0);
   __syncthreads();
   for (int t = tid; t < P2; t += WB_THREADS) {
     if (t < len) {
@@ -137,14 +138,14 @@ __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const int *__restric
     const int c0 = r & ~255, clen = len - c0 < 256 ? len - c0 : 256;
     const unsigned long long key = key64[r];
     const int t = (int)(key & 8191u);
-    const int o = base + c0 + wb_deal(r & 255, clen);
+    const eoff o = base + c0 + wb_deal(r & 255, clen);
     wrd[o] = (unsigned)(key >> 21) | ((unsigned)rowl[t] << cbits);
     vout[o] = val[k0 + t];
   }
 }
 
 // fills w.wrd / w.val (allocated, zeroed) from the device CSR arrays; false = this matrix needs the host builder
-inline bool wave_fill_dev(WaveRowsDev &w, const int *d_ptr, const int *d_idx, const real *d_val, hipStream_t st, long long &distinct) {
+inline bool wave_fill_dev(WaveRowsDev &w, const eoff *d_ptr, const int *d_idx, const real *d_val, hipStream_t st, long long &distinct) {
   const int lshift = sizeof(real) == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
   const long long lines = ((long long)w.cols >> lshift) + 1;
   const int bm_words = (int)((lines + 31) / 32);
@@ -153,7 +154,7 @@ inline bool wave_fill_dev(WaveRowsDev &w, const int *d_ptr, const int *d_idx, co
   DevBuf<unsigned long long> cnt(1);
   auto launch = [&](auto kern) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(w.nunit), dim3(WB_THREADS), lds, st, d_ptr, d_idx, d_val, (const int *)w.urow.p, (const int *)w.useg.p,
+    hipLaunchKernelGGL(kern, dim3(w.nunit), dim3(WB_THREADS), lds, st, d_ptr, d_idx, d_val, (const int *)w.urow.p, (const eoff *)w.useg.p,
                        w.wrd.p, w.val.p, w.cbits, w.bshift, lshift, bm_words, cnt.p);
   };
   if (w.sub_window_order) launch(k_wave_layout<true>);
@@ -168,7 +169,7 @@ inline bool wave_fill_dev(WaveRowsDev &w, const int *d_ptr, const int *d_idx, co
 
 // the layout of `mat` (already uploaded as CSR): on the device when it can be, on the host otherwise; SCS_AMD_WR_BUILD = host | dev |
 // verify (both, compared byte for byte -- throws on any difference)
-inline void wave_build(WaveRowsDev &w, int rows, int cols, const int *hptr, const int *hidx, const real *hval, const CsrDev &mat,
+inline void wave_build(WaveRowsDev &w, int rows, int cols, const eoff *hptr, const int *hidx, const real *hval, const CsrDev &mat,
                        hipStream_t st) {
   int mode = 1; // dev
   if (const char *e = getenv("SCS_AMD_WR_BUILD")) mode = !strcmp(e, "host") ? 0 : (!strcmp(e, "verify") ? 2 : 1);
