@@ -38,8 +38,9 @@
  * include/scs_types.h:13-32).  scs_int is 32-bit by default and 64-bit when the
  * header is compiled with -DDLONG, exactly like the reference's own switch; the
  * matching library is libscsamd_dlong.so (same entry points, 64-bit indices and
- * sizes at this boundary; the device keeps 32-bit indices, so a problem still
- * needs nnz(A) < 2^31 and scs_init refuses larger ones loudly).
+ * sizes at this boundary; on the device row / column indices stay 32-bit --
+ * m + n + 1 < 2^31, refused loudly otherwise -- and entry positions are 64-bit
+ * in that build, so nnz(A) >= 2^31 is accepted).
  */
 #ifndef SCS_AMD_H
 #define SCS_AMD_H
