@@ -588,9 +588,13 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
         auto la_prepare = [&]() {
           const PsdRot up = lane_shift1<true>(mine), dn = lane_shift1<false>(mine);
           if (lane < npairs) {
-            const bool edge = lane == 0 || lane == npairs - 1;
-            const PsdRot rec_p = edge ? mine : up, rec_q = lane == 0 ? up : dn;
-            psd_la_prepare(plan, rec_p, rec_q, pos_a, pos_b, ld);
+            // pair i of the next step takes its first player from pair i + 1 (the last pair: from itself) and its second from pair
+            // i - 1.  Pair 0 is the exception (player 0 stays, the other comes from pair 1): it names its players the other way round,
+            // so that for EVERY lane the first record is the upper neighbour's and the second the lower one's -- lane 0's own, because a
+            // shift down leaves the first lane its own value.  (Pairs are unordered; one select less per record field.)
+            const PsdRot rec_p = lane == npairs - 1 ? mine : up;
+            const int p = lane == 0 ? pos_b : pos_a, q = lane == 0 ? pos_a : pos_b;
+            psd_la_prepare(plan, rec_p, dn, p, q, ld);
           }
         };
         if (la) { // prologue: step 0 from the matrix as it stands
@@ -628,8 +632,8 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
               if (step + 2 < K2 - 1) la_prepare(); // for the phase after the barrier
             }
           } else {
-            rotates = rot_any[par] != 0; // uniform
-            psd_update_pass<NB>(Acur, Anext, V, tq, tc, items, ld, rotates); // loads first, `rotates` is only needed for the stores
+            psd_update_pass<NB>(Acur, Anext, V, tq, tc, items, ld, rot_any + par); // the flag is read with the tables: one LDS round trip
+            rotates = rot_any[par] != 0; // uniform (the same word: already in a register)
           }
 #ifdef SCSAMD_PSD_CLOCKS
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

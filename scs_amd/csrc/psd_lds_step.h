@@ -126,25 +126,41 @@ PSD_HD int psd_sym_index(int r, int c, int ld) { return r < c ? r * ld + c : c *
 // entry is read and written by the same lane); the pipelined step passes the other copy.
 template <int NB>
 PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB> &it,
-                            int ld, bool rotates = true) {
+                            int ld, const int *rotates_flag = nullptr) {
+  // pipelined step: "does this step rotate at all" is a word in LDS; it is asked for together with the tables (ONE round trip for the
+  // flag, the block's two pairs and the row pairs' pair -- left alone the compiler reads the flag, waits, branches, reads the block's
+  // tables, waits, reads the rows' table, waits: four dependent round trips per step where two are needed)
+  int flag = rotates_flag ? *rotates_flag : 1;
   constexpr int NV = 3 * NB;
   int i11[NB], i12[NB], i21[NB], i22[NB];
   RotCS r1[NB], r2[NB];
+  PsdPair q1[NB], q2[NB];
   bool diag[NB];
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
-    const PsdPair pq1 = rot_pq[it.bP[u]], pq2 = rot_pq[it.bQ[u]];
+    q1[u] = rot_pq[it.bP[u]];
+    q2[u] = rot_pq[it.bQ[u]];
     r1[u] = rot_cs[it.bP[u]];
     r2[u] = rot_cs[it.bQ[u]];
+  }
+  PsdPair pqv = rot_pq[it.vQ];
+  RotCS rq = rot_cs[it.vQ];
+#ifndef PSD_STEP_HOST_CHECK
+  // the flag and every table entry: one batch of LDS reads, one wait
+  asm volatile("" : "+v"(flag), "+v"(pqv.x), "+v"(pqv.y), "+v"(rq.c), "+v"(rq.s));
+  PSD_UNROLL
+  for (int u = 0; u < NB; ++u)
+    asm volatile("" : "+v"(q1[u].x), "+v"(q1[u].y), "+v"(q2[u].x), "+v"(q2[u].y), "+v"(r1[u].c), "+v"(r1[u].s), "+v"(r2[u].c), "+v"(r2[u].s));
+#endif
+  PSD_UNROLL
+  for (int u = 0; u < NB; ++u) {
     diag[u] = it.bP[u] == it.bQ[u];
-    i11[u] = psd_sym_index(pq1.x, pq2.x, ld);
-    i12[u] = psd_sym_index(pq1.x, pq2.y, ld);
-    i21[u] = psd_sym_index(pq1.y, pq2.x, ld); // diagonal block: the same stored entry as i12 (x < y)
-    i22[u] = psd_sym_index(pq1.y, pq2.y, ld);
+    i11[u] = psd_sym_index(q1[u].x, q2[u].x, ld);
+    i12[u] = psd_sym_index(q1[u].x, q2[u].y, ld);
+    i21[u] = psd_sym_index(q1[u].y, q2[u].x, ld); // diagonal block: the same stored entry as i12
+    i22[u] = psd_sym_index(q1[u].y, q2[u].y, ld);
   }
   int ip[NV], iq[NV];
-  const PsdPair pqv = rot_pq[it.vQ];
-  const RotCS rq = rot_cs[it.vQ];
   PSD_UNROLL
   for (int j = 0; j < NV; ++j) {
     ip[j] = it.vI[j] * ld + pqv.x;
@@ -163,9 +179,8 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
     vp[j] = V[ip[j]];
     vq[j] = V[iq[j]];
   }
-  // (pipelined step: `rotates` comes out of LDS too -- asked for before the tables, needed only here, so that its round trip rides
-  // along with the loads instead of preceding them; a step that rotates nothing stores nothing)
-  if (!rotates) return;
+  // (a step that rotates nothing stores nothing)
+  if (!flag) return;
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
     if (it.okb[u]) {

@@ -111,9 +111,12 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
             if (!((q0[sp].x == pa[i] || q0[sp].y == pa[i]) && (q0[sq].x == pb[i] || q0[sq].y == pb[i]))) ++mism;
             // the kernel: lane i + 1's record by a DPP shift up, lane i - 1's by a shift down (lane 0 and the last lane use their own)
             const PsdRot &up = prev[i + 1 < npairs ? i + 1 : i], &dn = prev[i > 0 ? i - 1 : i];
-            const PsdRot &rec_p = (i == 0 || i == npairs - 1) ? prev[i] : up, &rec_q = i == 0 ? up : dn;
-            if (&rec_p != &prev[sp] || &rec_q != &prev[sq]) ++mism;
-            nany |= psd_lookahead_rec(Acur, rec_p, rec_q, pa[i], pb[i], ld, k, thr, offmax, mine[i]);
+            // (lane 0 names its players the other way round, so that every lane's first record is `up` -- the last lane's its own -- and its
+            // second `dn`, which for lane 0 is its own record)
+            const PsdRot &rec_p = i == npairs - 1 ? prev[i] : up, &rec_q = dn;
+            const int p = i == 0 ? pb[i] : pa[i], q = i == 0 ? pa[i] : pb[i];
+            if (i == 0 ? (&rec_p != &prev[sq] || &rec_q != &prev[sp]) : (&rec_p != &prev[sp] || &rec_q != &prev[sq])) ++mism;
+            nany |= psd_lookahead_rec(Acur, rec_p, rec_q, p, q, ld, k, thr, offmax, mine[i]);
             psd_pair_advance(i, K2, pa[i], pb[i]);
             tq[(par ^ 1) * TBL + i] = PsdPair{mine[i].x, mine[i].y};
             tc[(par ^ 1) * TBL + i] = RotCS{mine[i].c, mine[i].s};
