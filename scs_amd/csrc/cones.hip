@@ -632,8 +632,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
               if (step + 2 < K2 - 1) la_prepare(); // for the phase after the barrier
             }
           } else {
-            psd_update_pass<NB>(Acur, Anext, V, tq, tc, items, ld, rot_any + par); // the flag is read with the tables: one LDS round trip
-            rotates = rot_any[par] != 0; // uniform (the same word: already in a register)
+            rotates = psd_update_pass<NB>(Acur, Anext, V, tq, tc, items, ld, rot_any + par) != 0; // the flag is read with the tables (uniform)
           }
 #ifdef SCSAMD_PSD_CLOCKS
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

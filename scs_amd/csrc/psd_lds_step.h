@@ -124,9 +124,10 @@ PSD_HD int psd_sym_index(int r, int c, int ld) { return r < c ? r * ld + c : c *
 // -- the LDS round trips of a lane's items overlap instead of queueing behind each other.  Items beyond the end are clamped to item
 // 0 for the loads and skipped by the stores (no per-item branches in the load phase).  A_dst == A_src is the in-place form (every
 // entry is read and written by the same lane); the pipelined step passes the other copy.
+// Returns the flag (1 without one).
 template <int NB>
-PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB> &it,
-                            int ld, const int *rotates_flag = nullptr) {
+PSD_HD int psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB> &it,
+                           int ld, const int *rotates_flag = nullptr) {
   // pipelined step: "does this step rotate at all" is a word in LDS; it is asked for together with the tables (ONE round trip for the
   // flag, the block's two pairs and the row pairs' pair -- left alone the compiler reads the flag, waits, branches, reads the block's
   // tables, waits, reads the rows' table, waits: four dependent round trips per step where two are needed)
@@ -180,7 +181,7 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
     vq[j] = V[iq[j]];
   }
   // (a step that rotates nothing stores nothing)
-  if (!flag) return;
+  if (!flag) return 0;
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
     if (it.okb[u]) {
@@ -207,6 +208,7 @@ PSD_HD void psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair
       V[iq[j]] = rq.s * vp[j] + rq.c * vq[j];
     }
   }
+  return flag;
 }
 
 // the players of pair i at the round-robin positions (pos_a, pos_b), and the positions of the next step (player 0 never moves;
