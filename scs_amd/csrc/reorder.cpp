@@ -1,5 +1,7 @@
 // reorder.cpp -- see reorder.h.  Host code, setup time only (scs_init).
 #include "reorder.h"
+#include <thread>
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <numeric>
@@ -104,9 +106,11 @@ void measure(const HostCsc &A, Candidate &c) {
   }
   std::vector<eoff> tp;
   std::vector<int> ti;
+  // (the two measurements are independent passes over read-only patterns: one of them on a second host thread)
+  std::thread side([&] { c.after[1] = lines_per_entry(np.data(), ni.data(), n, m, sizeof(real)); });
   transpose_pattern(np.data(), ni.data(), n, m, tp, ti);
-  c.after[1] = lines_per_entry(np.data(), ni.data(), n, m, sizeof(real));
   c.after[0] = lines_per_entry(tp.data(), ti.data(), m, n, sizeof(real));
+  side.join();
 }
 
 } // namespace
@@ -175,22 +179,33 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   }
   std::vector<eoff> rptr; // CSR pattern of A (rows -> columns)
   std::vector<int> rcol;
+  std::atomic<int> verdict{0}; // 0: not known yet, 1: go on, 2: the given numbering is already local
+  std::thread tb0([&] { R.before[1] = lines_per_entry(cp, ci, n, m, sizeof(real)); }); // A' product: rows = columns of A, gathers y
   transpose_pattern(cp, ci, n, m, rptr, rcol);
-  R.before[1] = lines_per_entry(cp, ci, n, m, sizeof(real));                    // A' product: rows = columns of A, gathers y
-  R.before[0] = lines_per_entry(rptr.data(), rcol.data(), m, n, sizeof(real)); // A product: rows of A, gathers x
-  const double before = 0.5 * (R.before[0] + R.before[1]);
+  // The line sharing of the GIVEN numbering is measured on a side thread while this one already starts on the candidates; if it turns
+  // out local enough (the common case for problems that come in a sensible order) the searches are told to stop and their work --
+  // at most the ~0.15 s the measurement takes -- is dropped.
   // (0.25, not the 0.8 at which spmv_wave.h switches kernels: rows that keep their place re-use a few columns many times and
   // so share lines in ANY numbering of the variables -- a scrambled band measures 0.49 / 0.94 -- while the rest gains 10x)
-  if (before <= 0.25 && force != 1) {
-    R.why = "the given numbering is already local";
-    R.seconds = now_s() - t0;
-    return;
-  }
+  std::thread tb([&] {
+    R.before[0] = lines_per_entry(rptr.data(), rcol.data(), m, n, sizeof(real)); // A product: rows of A, gathers x
+    tb0.join();
+    verdict.store(0.5 * (R.before[0] + R.before[1]) <= 0.25 && force != 1 ? 2 : 1, std::memory_order_release);
+  });
+  // The candidates are independent of each other (read-only A, rptr / rcol, ckey): candidate 1 is built and measured on a second
+  // host thread while this one runs the graph search of candidate 2 (round 5: 1.17 -> ~0.6 s of scs_init at n = 1e6, same decisions).
+  const bool dbg_t = getenv("SCS_AMD_DEBUG") != nullptr;
+  if (dbg_t) fprintf(stderr, "[scs_amd reorder] first pass + transpose: %.0f ms\n", 1e3 * (now_s() - t0));
   std::vector<Candidate> cands;
+  Candidate c1;
+  bool have_c1 = false;
+  std::thread t1;
   // ---- candidate 1: anchors.  A column is keyed by the mean position of its entries in rows that cannot move (only when every
   // column has such entries: the rest would need the graph search anyway), a free row by the mean NEW position of its columns.
   if (many_anchors && unkeyed == 0) {
-    Candidate c;
+    have_c1 = true;
+    t1 = std::thread([&] {
+    Candidate &c = c1;
     c.method = "anchors (mean position of a column's entries in the rows that cannot move)";
     c.col_new2old = order_by_key(ckey);
     std::vector<int> col_old2new((size_t)n);
@@ -206,8 +221,8 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
       if (cnt) rkey[i] = s / cnt;
     }
     place_free_rows(rkey, z, lp, m, c.row_new2old);
-    measure(A, c);
-    cands.push_back(std::move(c));
+    if (verdict.load(std::memory_order_acquire) != 2) measure(A, c);
+    });
   }
   // ---- candidate 2: breadth-first (Cuthill-McKee) numbering of the bipartite graph (vertices 0..n-1 = columns, n..n+m-1 = rows),
   // every connected component from a pseudo-peripheral start; columns take the visiting order, free rows follow it inside their
@@ -225,6 +240,20 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
       mark[start] = tag;
       int last = start;
       while (head < q.size()) {
+        if ((head & 0xFFFF) == 0 && verdict.load(std::memory_order_relaxed) == 2) return -1; // told to stop (see above)
+        // the search is bound by the latency of its scattered reads (one of `mark` per edge): the marks of the neighbours of the vertex
+        // two places down the queue, and the adjacency of the one six places down, are asked for now
+        if (head + 6 < q.size()) {
+          const int w = q[head + 6];
+          __builtin_prefetch(w < n ? (const void *)&ci[cp[w]] : (const void *)&rcol[rptr[w - n]]);
+        }
+        if (head + 2 < q.size()) {
+          const int w = q[head + 2];
+          if (w < n)
+            for (eoff e = cp[w]; e < cp[w + 1]; ++e) __builtin_prefetch(&mark[(size_t)n + ci[e]]);
+          else
+            for (eoff e = rptr[w - n]; e < rptr[w - n + 1]; ++e) __builtin_prefetch(&mark[rcol[e]]);
+        }
         const int v = q[head++];
         last = v;
         if (v < n) {
@@ -253,20 +282,43 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     for (size_t s = 0; s < nv; ++s) {
       if (done[s]) continue;
       scratch.clear();
+      if (verdict.load(std::memory_order_relaxed) == 2) break;
       const int far = bfs((int)s, tag++, scratch); // pseudo-peripheral start: the last vertex a search from s reaches (a band is walked to its
                                                    // farther end; a second search from there measured the same line sharing and a quarter more time)
+      if (far < 0) break;
       const size_t first = order.size();
-      bfs(far, tag++, order);
+      if (bfs(far, tag++, order) < 0) break;
       for (size_t q = first; q < order.size(); ++q) done[order[q]] = 1;
     }
-    std::vector<double> rkey((size_t)m, -1.0);
-    c.col_new2old.reserve(n);
-    for (size_t q = 0; q < order.size(); ++q) {
-      if (order[q] < n) c.col_new2old.push_back(order[q]);
-      else rkey[order[q] - n] = (double)q;
+    tb.join();
+    if (verdict.load(std::memory_order_acquire) == 2) {
+      if (have_c1) t1.join();
+      R.why = "the given numbering is already local";
+      R.seconds = now_s() - t0;
+      return;
     }
-    place_free_rows(rkey, z, lp, m, c.row_new2old);
+    // every vertex is visited (all components are walked): the free rows take the visiting order inside their ranges directly -- what
+    // place_free_rows does with the visiting rank as the key, without the two sorts (180 ms of 1.17 s at n = 1e6)
+    c.col_new2old.reserve(n);
+    c.row_new2old.resize((size_t)m);
+    std::iota(c.row_new2old.begin(), c.row_new2old.end(), 0);
+    size_t o0 = 0, o1 = (size_t)z;
+    for (size_t q = 0; q < order.size(); ++q) {
+      if (order[q] < n) {
+        c.col_new2old.push_back(order[q]);
+      } else {
+        const int i = order[q] - n;
+        if (i < z) c.row_new2old[o0++] = i;
+        else if (i < z + lp) c.row_new2old[o1++] = i;
+      }
+    }
+    if (dbg_t) fprintf(stderr, "[scs_amd reorder] graph search + row placement done at %.0f ms\n", 1e3 * (now_s() - t0));
     measure(A, c);
+    if (dbg_t) fprintf(stderr, "[scs_amd reorder] candidate 2 measured at %.0f ms\n", 1e3 * (now_s() - t0));
+    if (have_c1) { // (candidate 1 first, as before: ties go to it)
+      t1.join();
+      cands.push_back(std::move(c1));
+    }
     cands.push_back(std::move(c));
   }
   size_t best = 0;
@@ -277,6 +329,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   R.after[1] = c.after[1];
   R.method = c.method;
   R.seconds = now_s() - t0;
+  const double before = 0.5 * (R.before[0] + R.before[1]); // (tb was joined after the graph search)
   if (0.5 * (c.after[0] + c.after[1]) <= 0.8 * before) {
     R.active = true;
     R.col_new2old = std::move(c.col_new2old);
@@ -302,19 +355,27 @@ void apply_reorder(HostCsc &A, const Reorder &R) {
   B.i.resize(A.i.size());
   B.x.resize(A.x.size());
   for (int j = 0; j < n; ++j) B.p[j + 1] = B.p[j] + (A.p[R.col_new2old[j] + 1] - A.p[R.col_new2old[j]]);
-  std::vector<std::pair<int, real>> col;
-  for (int j = 0; j < n; ++j) {
-    const int jo = R.col_new2old[j];
-    col.clear();
-    for (eoff q = A.p[jo]; q < A.p[jo + 1]; ++q) col.emplace_back(row_old2new[A.i[q]], A.x[q]);
-    std::stable_sort(col.begin(), col.end(), [](const std::pair<int, real> &a, const std::pair<int, real> &b) { return a.first < b.first; });
-    eoff o = B.p[j];
-    for (const auto &e : col) {
-      B.i[(size_t)o] = e.first;
-      B.x[(size_t)o] = e.second;
-      ++o;
+  // columns are independent once B.p is known: ranges of them on a few host threads
+  auto do_range = [&](int j0, int j1) {
+    std::vector<std::pair<int, real>> col;
+    for (int j = j0; j < j1; ++j) {
+      const int jo = R.col_new2old[j];
+      col.clear();
+      for (eoff q = A.p[jo]; q < A.p[jo + 1]; ++q) col.emplace_back(row_old2new[A.i[q]], A.x[q]);
+      std::stable_sort(col.begin(), col.end(), [](const std::pair<int, real> &a, const std::pair<int, real> &b) { return a.first < b.first; });
+      eoff o = B.p[j];
+      for (const auto &e : col) {
+        B.i[(size_t)o] = e.first;
+        B.x[(size_t)o] = e.second;
+        ++o;
+      }
     }
-  }
+  };
+  const int nthr = n >= 100000 ? 4 : 1;
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nthr; ++t) pool.emplace_back(do_range, (int)((long long)n * t / nthr), (int)((long long)n * (t + 1) / nthr));
+  do_range(0, (int)((long long)n / nthr));
+  for (std::thread &th : pool) th.join();
   A = std::move(B);
 }
 
