@@ -833,24 +833,22 @@ def secondary_single_gpu(args, headline_prob=None):
         except Exception as e:
             out["locality_variant"][f"band_{band}"] = dict(error=repr(e))
     try:
-        from scs_amd import problems
+        from scs_amd import capi, problems
         scr = problems.scramble_prob(band_pr, 7)
         band_pr = None
         prob_scr = None
         for label, env in (("permuted_band_1024", None), ("permuted_band_1024_as_given", "0")):
-            if env is None:
-                os.environ.pop("SCS_AMD_REORDER", None)
-            else:
-                os.environ["SCS_AMD_REORDER"] = env
+            capi.load("libscsamd.so")
+            capi.set_option("reorder", env)  # scs_amd_set_option: read by the next scs_init (None = the library's own decision)
             try:
                 s = HipSolver(args, 0, 0, args.n, 2 * args.n, args.col_nnz, args.seed, 0, 1e-4, pr=scr, prob=prob_scr)
                 prob_scr = s.prob
                 locality_run(label, s, "the band-1024 problem with its variables and the rows of its zero / nonnegative cones randomly "
-                                       "permuted" + (" -- renumbering switched off (SCS_AMD_REORDER=0)" if env == "0" else
+                                       "permuted" + (" -- renumbering switched off (option reorder=0)" if env == "0" else
                                                      " -- scs_init renumbers (Cuthill-McKee on the row / column graph, reorder.h)"))
                 s.close()
             finally:
-                os.environ.pop("SCS_AMD_REORDER", None)
+                capi.set_option("reorder", None)
     except Exception as e:
         out["locality_variant"]["permuted_band_1024"] = dict(error=repr(e))
     return out

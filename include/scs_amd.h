@@ -412,6 +412,19 @@ void scs_amd_shard_free(ScsAmdShard *h);
  * scs_solve returns SCS_FAILED with a NaN-filled solution and the SIGINT handler restored, scs_solve_lin_sys returns
  * non-zero, and the library stays usable.  Returns the countdown that was armed before the call. */
 long long scs_amd_test_fail_at(long long k);
+/* ---- options (scs_amd/csrc/options.h holds the table; INTEGRATION.md section 5 prints it) ---------------------------------
+ * The reference steers everything through ScsSettings (include/scs.h:61-101) and reads no environment variable.  This
+ * library's own switches -- which implementation (host / device) of a step, which kernel schedule -- go through ONE entry:
+ *   scs_amd_set_option("reorder", "0")   process-wide; takes effect for workspaces created AFTERWARDS (scs_init,
+ *                                        scs_init_lin_sys_work, _scs_init_cone); value NULL = back to the default.
+ *                                        Returns 0, or -1 for a key that is not in the table.
+ *   scs_amd_get_option("reorder")        the value in force, NULL at the default (or for an unknown key)
+ *   scs_amd_list_options(buf, cap)       the table as text, one row per line (key, class, numerics, values, meaning)
+ * Environment fallback SCS_AMD_<KEY>: honoured for rows of class `supported` and `diag` only; rows of class `ab` (measurement
+ * variants) and `test` (test hooks) are reachable from the environment only when SCS_AMD_ALLOW_ENV_HOOKS=1 is also set. */
+scs_int scs_amd_set_option(const char *key, const char *value);
+const char *scs_amd_get_option(const char *key);
+scs_int scs_amd_list_options(char *buf, scs_int cap);
 /* free device memory (bytes) on the selected device after a device-wide synchronise, < 0 on failure */
 long long scs_amd_device_free_bytes(void);
 /* number of visible HIP devices, or <0 with no usable runtime (never throws) */

@@ -2,6 +2,7 @@
 # A/B of library variants built by scripts/build_variant.sh on ONE box: swaps scs_amd/lib/libscsamd.so, runs the size sweep, round robin
 # usage: scripts/ab_variants.sh "<cases>" <reps> <variant>...
 set -u
+export SCS_AMD_ALLOW_ENV_HOOKS=1 # A/B script: measurement variants of scs_amd/csrc/options.h are set through the environment
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/ab
 mkdir -p $OUT

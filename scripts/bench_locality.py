@@ -4,6 +4,7 @@ cones and data law on a banded pattern (scs_amd/problems.py banded_rows), for se
 software-pipelined instantiation of csr_wave_kernel (SCS_AMD_WR_PIPE=0|1; unset = the library's own choice).
 One JSON line per (band, mode).   python scripts/bench_locality.py [--n 1000000] [--bands 4096,65536,0]"""
 import argparse, json, os, sys, time
+os.environ["SCS_AMD_ALLOW_ENV_HOOKS"] = "1"  # A/B script: the measurement variants of scs_amd/csrc/options.h are set through the environment
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1000000)

@@ -4,6 +4,7 @@ kernel (environment switches read by scs_init), for the decision which one the l
     python scripts/bench_spmv_modes.py --cases 1000000:f64:0,200000:f64:0,4000000:f32:0,1000000:f64:1024 --modes plain,ls16,ls8
 One JSON line per (case, mode)."""
 import argparse, json, os, sys, time
+os.environ["SCS_AMD_ALLOW_ENV_HOOKS"] = "1"  # A/B script: the measurement variants of scs_amd/csrc/options.h are set through the environment
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default="1000000:f64:0")

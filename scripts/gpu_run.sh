@@ -10,6 +10,7 @@
 #   term:<n>:<threads>         scripts/term_parity.py in the BACKGROUND (its CPU leg runs beside the later steps); waited for at the end
 #   sh:<command>               anything else, verbatim
 set -u
+export SCS_AMD_ALLOW_ENV_HOOKS=1 # A/B script: measurement variants of scs_amd/csrc/options.h are set through the environment
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:?tag}; shift
 OUT=$R/gpurun_out/$TAG

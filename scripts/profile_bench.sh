@@ -4,6 +4,7 @@
 #   2. PMC pass FETCH_SIZE             (separate pass: counter slots; never combined with tracing domains other than kernel-trace)
 #   3. PMC pass WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 set -u
+export SCS_AMD_ALLOW_ENV_HOOKS=1 # A/B script: measurement variants of scs_amd/csrc/options.h are set through the environment
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 ROUND=${1:-r3}
 OUT=$R/gpurun_out/prof_$ROUND

@@ -3,6 +3,7 @@
 # BASELINE configs[2] (LDS Jacobi kernel) and on 8 blocks of 256x256 (chip-wide path, psd_big.h).  SCS_AMD_GRAPH=0: rocprofv3
 # crashes on replayed HIP-graph kernel nodes.  Counters only with --kernel-trace (no other trace domain).
 set -u
+export SCS_AMD_ALLOW_ENV_HOOKS=1 # A/B script: measurement variants of scs_amd/csrc/options.h are set through the environment
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_psd
 mkdir -p $OUT

@@ -5,6 +5,7 @@ OUT=$R/gpurun_out/prof_psd_blocked
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export SCS_AMD_GRAPH=0
+export SCS_AMD_ALLOW_ENV_HOOKS=1
 rocprofv3 --kernel-trace --stats -d $OUT/tr -o t -- python $R/scripts/bench_psd_sizes.py --cases 1024x1,512x2,256x8,92x64 --iters 20 > $OUT/psd_traced.out 2> $OUT/psd_traced.err
 CTRS="SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES"
 rocprofv3 --kernel-trace --pmc $CTRS -d $OUT/pmc -o p -- python $R/scripts/bench_psd_sizes.py --cases 256x8 --iters 10 > $OUT/psd_pmc.out 2> $OUT/psd_pmc.err

@@ -3,6 +3,7 @@
 # (scripts/build_variant.sh psdclk -DSCSAMD_PSD_CLOCKS, built beforehand -- it travels with the snapshot) swapped in for the run,
 # pipelined step (SCS_AMD_PSD_PIPE=1, shipped) and two-phase step (=0) back to back.  Output: gpurun_out/<tag>/psd_clocks.md
 set -u
+export SCS_AMD_ALLOW_ENV_HOOKS=1 # A/B script: measurement variants of scs_amd/csrc/options.h are set through the environment
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${1:-psdclk}
 mkdir -p $OUT

@@ -147,6 +147,12 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]  # device pointers
         lib.scs_amd_linsys_sync.restype = scs_int
         lib.scs_amd_linsys_sync.argtypes = [C.c_void_p]
+        lib.scs_amd_set_option.restype = scs_int
+        lib.scs_amd_set_option.argtypes = [C.c_char_p, C.c_char_p]
+        lib.scs_amd_get_option.restype = C.c_char_p
+        lib.scs_amd_get_option.argtypes = [C.c_char_p]
+        lib.scs_amd_list_options.restype = scs_int
+        lib.scs_amd_list_options.argtypes = [C.c_char_p, scs_int]
         lib.scs_amd_device_free_bytes.restype = C.c_longlong
         lib.scs_amd_device_free_bytes.argtypes = []
         lib.scs_amd_test_fail_at.restype = C.c_longlong
@@ -226,6 +232,28 @@ def load(name="libscsamd.so"):
     bind_api(lib, T, full=not only_linsys, linsys=True, cones=not only_linsys, stats=True)
     _cache[name] = lib
     return lib
+
+
+def set_option(key, value, libs=None):
+    """scs_amd_set_option on every product library loaded so far (each shared object keeps its own table): process-wide,
+    in force for workspaces created afterwards.  value None = back to the default.  Raises on a key the table does not hold."""
+    for name, lib in list(_cache.items()) if libs is None else [(None, l) for l in libs]:
+        rc = lib.scs_amd_set_option(key.encode(), None if value is None else str(value).encode())
+        if rc != 0:
+            raise KeyError(f"scs_amd: unknown option {key!r}")
+
+
+def list_options(lib=None):
+    """The option table of scs_amd/csrc/options.h as a list of dicts (key, cls, numerics, values, doc)."""
+    lib = lib or load("libscsamd.so")
+    n = lib.scs_amd_list_options(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.scs_amd_list_options(buf, n + 1)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        k, cls, num, vals, doc = line.split("\t")
+        rows.append(dict(key=k, cls=cls, numerics=int(num), values=vals, doc=doc))
+    return rows
 
 
 # ---- numpy <-> struct helpers ---------------------------------------------------

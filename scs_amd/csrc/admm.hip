@@ -1114,7 +1114,7 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
     w->k.cs = w->ccs.data();
     if (k->psize) w->cpw.assign(k->p, k->p + k->psize);
     w->k.p = w->cpw.data();
-    const bool dbg = getenv("SCS_AMD_DEBUG") != nullptr;
+    const bool dbg = opt_get("debug") != nullptr;
     double tp = now_ms();
     auto phase = [&](const char *what) {
       if (dbg) fprintf(stderr, "[scs_amd init] %-22s %8.1f ms\n", what, now_ms() - tp);
@@ -1136,7 +1136,7 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
       // 26 streaming passes over nnz: on the device once the matrix is big enough for
       // the ~200 launches to be cheaper than the host loops (SCS_AMD_EQUIL=host|dev forces)
       bool dev_eq = (long long)d->A->p[n] >= 100000;
-      if (const char *e = getenv("SCS_AMD_EQUIL")) dev_eq = strcmp(e, "host") != 0;
+      if (const char *e = opt_get("equil")) dev_eq = strcmp(e, "host") != 0;
       if (dev_eq) equilibrate_dev(w->has_P ? &w->P : nullptr, w->A, &w->k, w->scal, w->stream, &a_pattern);
       else equilibrate(w->has_P ? &w->P : nullptr, w->A, &w->k, w->scal);
     } else {
@@ -1186,7 +1186,7 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
       // host path (a handful of stream syncs would cost more than the arithmetic).
       // SCS_AMD_AA=host|dev forces either.
       bool dev_aa = l >= 32768;
-      if (const char *e = getenv("SCS_AMD_AA")) dev_aa = strcmp(e, "host") != 0;
+      if (const char *e = opt_get("aa")) dev_aa = strcmp(e, "host") != 0;
       if (dev_aa) {
         w->accel_dev = aa_dev_init(l, w->stgs.acceleration_lookback, w->stgs.acceleration_lookback,
                                    w->stgs.acceleration_type_1, w->stgs.acceleration_regularization,

@@ -21,6 +21,7 @@
 #include <atomic>
 
 #include "../../include/scs_amd.h"
+#include "options.h"
 
 namespace scsamd {
 

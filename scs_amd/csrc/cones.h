@@ -22,6 +22,7 @@ struct ConeDev {
   // box cone
   DevBuf<real> bl, bu;      // bsize-1 each (already D-normalised, +-inf applied)
   DevBuf<real> box_t;       // [0] Newton warm start (reference c->box_t_warm_start)
+  bool psd_pipe = true;     // pipelined step of k_psd_jacobi (option psd_pipe, read in init)
   bool box_multi = false;   // large box: Newton steps as chip-wide launches (k_box_step), else one workgroup (k_box)
   DevBuf<real> box_part, box_ctl;
   // second-order cones

@@ -902,7 +902,7 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   }
   box_t.alloc(1);
   box_multi = bsize - 1 >= BOX_MULTI_MIN;
-  if (const char *e = getenv("SCS_AMD_BOX_MULTI")) box_multi = atoi(e) != 0 && bsize > 1; // tests force either path
+  if (const char *e = opt_get("box_multi")) box_multi = atoi(e) != 0 && bsize > 1; // tests force either path
   if (box_multi) {
     box_part.alloc((size_t)4 * BOX_MULTI_GRID);
     box_ctl.alloc(8); // one BoxCtl
@@ -981,13 +981,15 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
     psd_big->init(pk, PSD_LDS_KMAX, stream);
   }
   psd_calls = 0;
+  psd_pipe = true;
+  if (const char *e = opt_get("psd_pipe")) psd_pipe = atoi(e) != 0;
   // warm start of the LDS kernel: sized and gated by the largest block that kernel handles (blocks beyond the LDS path
   // carry their own basis in psd_big, and must not switch the small blocks' warm start off)
   psd_vprev.release();
   psd_tscratch.release();
   int warm_kmax = PSD_LDS_KMAX; // round 4: every order of the LDS kernel is warm started (SCS_AMD_PSD_WARM_KMAX=72 restores round 3's gate)
-  if (const char *e = getenv("SCS_AMD_PSD_WARM_KMAX")) warm_kmax = std::max(0, std::min(PSD_LDS_KMAX, atoi(e)));
-  if (n_psd && psd_lds_kmax >= 2 && psd_lds_kmax <= warm_kmax && !getenv("SCS_AMD_PSD_COLD")) {
+  if (const char *e = opt_get("psd_warm_kmax")) warm_kmax = std::max(0, std::min(PSD_LDS_KMAX, atoi(e)));
+  if (n_psd && psd_lds_kmax >= 2 && psd_lds_kmax <= warm_kmax && !opt_get("psd_cold")) {
     const size_t per_cone = (size_t)((psd_lds_kmax + 1) & ~1) * (((psd_lds_kmax + 1) & ~1) | 1);
     psd_vprev.alloc((size_t)n_psd * per_cone);
     if (psd_lds_kmax > PSD_WARM_KMAX) psd_tscratch.alloc((size_t)n_psd * per_cone); // T = A Vp of the warm start does not fit LDS
@@ -1038,8 +1040,7 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
     const int K2l = (lds_kmax + 1) & ~1;
     const bool carry = psd_vprev.p != nullptr;
     // round 5: pipelined step (second copy of A in LDS) whenever three matrices fit; SCS_AMD_PSD_PIPE=0 keeps the two-phase step (A/B)
-    static const bool pipe_env = [] { const char *e = getenv("SCS_AMD_PSD_PIPE"); return !e || atoi(e) != 0; }();
-    const int pipe = (pipe_env && K2l <= PSD_WARM_KMAX) ? 1 : 0;
+    const int pipe = (psd_pipe && K2l <= PSD_WARM_KMAX) ? 1 : 0; // psd_pipe: option read in init
     const size_t lds = PSD_LDS_HEADER + (size_t)((pipe || (carry && !psd_tscratch.p)) ? 3 : 2) * K2l * (K2l | 1) * sizeof(real);
     const int warm = carry && (psd_calls % PSD_WARM_RESET) != 0;
     ++psd_calls;

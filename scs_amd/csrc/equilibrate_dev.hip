@@ -233,7 +233,7 @@ void equilibrate_dev(HostCsc *P, HostCsc &A, const ScsCone *k, Scaling &sc, hipS
   cx.upload(A.x.data(), (size_t)nnz, st);
   // ---- pattern transpose: CSR(A) row pointers, column indices and the CSC position of every CSR entry
   int tr_mode = 1; // device
-  if (const char *e = getenv("SCS_AMD_TRANSPOSE")) tr_mode = !strcmp(e, "host") ? 0 : (!strcmp(e, "verify") ? 2 : 1);
+  if (const char *e = opt_get("transpose")) tr_mode = !strcmp(e, "host") ? 0 : (!strcmp(e, "verify") ? 2 : 1);
   auto host_transpose_pattern = [&](CsrPattern &H) { // counting sort; columns ascending inside each row
     H.rp.assign((size_t)m + 1, 0);
     H.rj.resize((size_t)nnz);

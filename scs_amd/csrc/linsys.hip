@@ -33,8 +33,9 @@ static_assert(PART_CAP >= SPMV_MAX_GRID && PART_CAP >= WR_MAX_GRID && PART_CAP >
 CsrDev::~CsrDev() { delete wave; }
 
 static inline int vec_grid(long long len) {
+  // read once per process (called per launch: no table lookups here); tests that shrink it run in their own process
   static const int cap = [] {
-    const char *e = getenv("SCS_AMD_VEC_MAX_GRID"); // tests shrink it to force grid-striding
+    const char *e = opt_get("vec_max_grid"); // tests shrink it to force grid-striding
     int g = e ? atoi(e) : VEC_MAX_GRID;
     return (g >= 1 && g <= PART_CAP / 2) ? g : VEC_MAX_GRID; // z'r and |r| partials share one PART_CAP array (measurement sweeps go to 2048)
   }();
@@ -938,7 +939,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
   }
-  const bool dbg_t = getenv("SCS_AMD_DEBUG") != nullptr;
+  const bool dbg_t = opt_get("debug") != nullptr;
   auto t_now = [] {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1037,7 +1038,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
     // measured: at n=1000/nnz=32000 one CU is already 3x slower than the multi-kernel path, so
     // this is for genuinely tiny systems only, where a CG iteration is pure launch latency
     use_fused = nnzA <= 4096 && n <= 1024 && m <= 4096;
-    if (const char *e = getenv("SCS_AMD_FUSED")) use_fused = atoi(e) != 0;
+    if (const char *e = opt_get("fused")) use_fused = atoi(e) != 0;
     // below this size a CG kernel is shorter than the host's cost of launching it: replay the
     // iterations from a captured graph instead (above it launches are hidden behind the kernels)
     // x, r and M are streamed once per CG iteration and nothing gathers from them: with the non-temporal policy they stop pushing
@@ -1045,16 +1046,16 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
     // per CG iteration (same bits); only where the matrices do not fit the Infinity Cache anyway.  SCS_AMD_VEC_NT = 0 | 1 | 3 (all
     // streams of the kernel: no better) forces a mode.
     nt_mode = nnzA >= 4000000 ? 1 : 0;
-    if (const char *e = getenv("SCS_AMD_VEC_NT")) nt_mode = atoi(e);
-    if (const char *e = getenv("SCS_AMD_DIR_MODE")) dir_mode = atoi(e);
+    if (const char *e = opt_get("vec_nt")) nt_mode = atoi(e);
+    if (const char *e = opt_get("dir_mode")) dir_mode = atoi(e);
     use_graph = nnzA <= CG_GRAPH_MAX_NNZ;
-    if (const char *e = getenv("SCS_AMD_GRAPH")) use_graph = atoi(e) != 0;
+    if (const char *e = opt_get("graph")) use_graph = atoi(e) != 0;
     // two launches per CG iteration (k_cg2_a + the transposed product): n small enough for p in LDS, no P
     // (k_cg2_a runs the A product through csr_stream_blocks and sums At.grid() partials: not with the wave-owned-rows
     // layout, whose GP product leaves a different partial count -- very tall A with n <= 1024 takes the four-kernel path)
     const bool no_wave = !(A.wave && A.wave->built) && !(At.wave && At.wave->built);
     use_cg2 = !use_fused && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
-    if (const char *e = getenv("SCS_AMD_CG2")) use_cg2 = atoi(e) != 0 && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
+    if (const char *e = opt_get("cg2")) use_cg2 = atoi(e) != 0 && !has_P && no_wave && n <= CG2_N_MAX && n >= 2 * RVW;
     // three launches per CG iteration (k_cg3_update), SCS_AMD_CG3=1: possible wherever the transposed product runs through the wave-owned-
     // rows kernels (their epilogue carries the two extra dot products)
     // (fp64 only: in fp32 the expansion behind beta loses ~eps x 10..100 relative, which is the size of fp32 CG's own rounding -- not worth
@@ -1064,7 +1065,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
     // and the re-reduction it removes are paid back by two more vector reads in the product's epilogue and one product enqueued past
     // convergence per solve) and it changes the rounding of every iterate -- not worth leaving the reference's recurrence for.
     use_cg3 = false;
-    if (const char *e = getenv("SCS_AMD_CG3")) use_cg3 = atoi(e) != 0 && cg3_ok;
+    if (const char *e = opt_get("cg3")) use_cg3 = atoi(e) != 0 && cg3_ok;
     if (use_cg3) use_graph = false;
     if (use_cg2) {
       p2.alloc(n);
@@ -1086,7 +1087,7 @@ void LinSys::init(const CscView *A_csc, const CscView *P_csc, hipStream_t s, Csr
   // -bias -- a kernel that narrows a position to 32 bits anywhere between the table and the load reads the wrong entry.  bias must be a
   // multiple of 4 (the wave kernels load 16 bytes of 4-byte words at a time).
   if (sizeof(eoff) == 8)
-    if (const char *e = getenv("SCS_AMD_TEST_OFFSET_BIAS")) {
+    if (const char *e = opt_get("test_offset_bias")) {
       const long long bias = atoll(e) & ~3LL;
       auto shift = [&](CsrDev &M) {
         if (M.rows <= 0 || bias == 0) return;
@@ -1302,7 +1303,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
                       real warm_scale) {
   const int gv = vec_grid(n), gnm = vec_grid((long long)n + m);
   CgCtl *c = ctl.p;
-  static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
+  static const bool debug = opt_get("debug") != nullptr;
   if (cg_x != b) { // the captured graph bakes the solution vector's address in
     if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
     cg_graph = nullptr;
@@ -1413,7 +1414,7 @@ int LinSys::solve_dev(real *b, const real *s, real tol, const real *warm_part, i
   }
   if (profiling) cg_timer.stop(cg_slot, stream);
   HIP_CHECK(hipGetLastError());
-  if (const char *tf = getenv("SCS_AMD_TRACE_FILE")) { // same record as oracle/trace_linsys.c
+  if (const char *tf = opt_get("trace_file")) { // same record as oracle/trace_linsys.c
     real x0 = 0;
     HIP_CHECK(hipMemcpyAsync(&x0, b, sizeof(real), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -1475,6 +1476,36 @@ long long scs_amd_device_free_bytes(void) {
 
 // test hook: arm (k >= 1) or disarm (k <= 0) the fault injection of common.h's hip_check; returns the previous countdown
 long long scs_amd_test_fail_at(long long k) { return fail_countdown().exchange(k > 0 ? k : 0); }
+
+// the options entry (options.h): process-wide, read when a workspace is created
+scs_int scs_amd_set_option(const char *key, const char *value) { return (scs_int)opt_set(key, value); }
+const char *scs_amd_get_option(const char *key) { return key ? opt_get(key) : nullptr; }
+// the table itself, one row per line "key<TAB>class<TAB>numerics<TAB>values<TAB>meaning": what INTEGRATION.md section 5 prints and
+// tests/test_options.py checks.  Returns the length needed (excluding the terminating zero); writes at most cap bytes.
+scs_int scs_amd_list_options(char *buf, scs_int cap) {
+  static const char *cls[] = {"supported", "ab", "test", "diag"};
+  int n;
+  const OptRow *r = opt_rows(&n);
+  std::string out;
+  for (int i = 0; i < n; ++i) {
+    out += r[i].key;
+    out += '\t';
+    out += cls[r[i].cls];
+    out += '\t';
+    out += (char)('0' + r[i].numerics);
+    out += '\t';
+    out += r[i].values;
+    out += '\t';
+    out += r[i].doc;
+    out += '\n';
+  }
+  if (buf && cap > 0) {
+    const size_t c = std::min(out.size(), (size_t)cap - 1);
+    memcpy(buf, out.data(), c);
+    buf[c] = 0;
+  }
+  return (scs_int)out.size();
+}
 
 const char *scs_get_lin_sys_method(void) { return "sparse-indirect-pcg-hip-gfx950"; }
 

@@ -1173,14 +1173,14 @@ struct BigPsd {
     nbig = (int)ids.size();
     if (!nbig) return;
     blocked = true;
-    if (const char *e = getenv("SCS_AMD_PSD_BLOCKED")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
+    if (const char *e = opt_get("psd_blocked")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
     ld = blocked ? (kmax + BJ_W - 1) / BJ_W * BJ_W : (kmax + 1) & ~1;
     cross = true;
-    if (const char *e = getenv("SCS_AMD_PSD_CROSS")) cross = atoi(e) != 0; // 0: full 63-step sweeps of every block-column pair (first form of round 3)
+    if (const char *e = opt_get("psd_cross")) cross = atoi(e) != 0; // 0: full 63-step sweeps of every block-column pair (first form of round 3)
     if (blocked) {
       const size_t npmax = (size_t)ld / BJ_W;
       fused = true;
-      if (const char *e = getenv("SCS_AMD_PSD_FUSED")) fused = atoi(e) != 0; // 0: inner sweep and update as two launches per outer step (A/B measurements)
+      if (const char *e = opt_get("psd_fused")) fused = atoi(e) != 0; // 0: inner sweep and update as two launches per outer step (A/B measurements)
       Qbuf.alloc((size_t)2 * nbig * npmax * BJ_W * BJ_W); // two generations (k_bj_fused)
       Sbuf.alloc((size_t)2 * nbig * npmax * BJ_W * BJ_W);
       Qflag.alloc((size_t)2 * nbig * npmax);
@@ -1192,7 +1192,7 @@ struct BigPsd {
     id.upload(ids.data(), ids.size(), st);
     A.alloc((size_t)nbig * ld * ld);
     V.alloc((size_t)nbig * ld * ld);
-    warm_ok = !getenv("SCS_AMD_PSD_COLD");
+    warm_ok = !opt_get("psd_cold");
     if (warm_ok) Vp.alloc((size_t)nbig * ld * ld);
     Tm.alloc((size_t)nbig * ld * ld); // T of the warm start, then the second copy of A during the sweeps
     have_basis = false;
@@ -1277,7 +1277,7 @@ struct BigPsd {
     sweeps_total += h_rem[1];
     sweeps_hint[warm ? 1 : 0] = h_rem[1];
     ++projections;
-    static const bool debug = getenv("SCS_AMD_DEBUG") != nullptr;
+    static const bool debug = opt_get("debug") != nullptr;
     if (debug) fprintf(stderr, "[scs_amd psd_big] projection %lld: %s start, sweeps so far %lld (this one %lld)\n", projections, warm ? "warm" : "cold", sweeps_total, sweeps_total - sweeps_before);
     if (warm_ok) {
       HIP_CHECK(hipMemcpyAsync(Vp.p, V.p, mat_bytes, hipMemcpyDeviceToDevice, st));

@@ -121,7 +121,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   const int m = A.m, n = A.n;
   const long long nnz = n > 0 ? A.p[n] : 0;
   int force = -1;
-  if (const char *e = getenv("SCS_AMD_REORDER")) force = atoi(e);
+  if (const char *e = opt_get("reorder")) force = atoi(e);
   if (force == 0) {
     R.why = "SCS_AMD_REORDER=0";
     return;
@@ -194,7 +194,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   });
   // The candidates are independent of each other (read-only A, rptr / rcol, ckey): candidate 1 is built and measured on a second
   // host thread while this one runs the graph search of candidate 2 (round 5: 1.17 -> ~0.6 s of scs_init at n = 1e6, same decisions).
-  const bool dbg_t = getenv("SCS_AMD_DEBUG") != nullptr;
+  const bool dbg_t = opt_get("debug") != nullptr;
   if (dbg_t) fprintf(stderr, "[scs_amd reorder] first pass + transpose: %.0f ms\n", 1e3 * (now_s() - t0));
   std::vector<Candidate> cands;
   Candidate c1;
@@ -338,7 +338,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   } else {
     R.why = "no candidate numbering improved the measured line sharing by 20 %";
   }
-  if (getenv("SCS_AMD_DEBUG"))
+  if (opt_get("debug"))
     fprintf(stderr, "[scs_amd reorder] %s: lines/entry A %.3f -> %.3f, A' %.3f -> %.3f, %s (%.0f ms)\n", R.method, R.before[0], R.after[0],
             R.before[1], R.after[1], R.active ? "kept" : "dropped", 1e3 * R.seconds);
 }

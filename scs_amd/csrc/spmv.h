@@ -268,7 +268,7 @@ struct CsrDev {
     build_row_blocks(hptr, s);
   }
   void build_row_blocks(const eoff *hptr, hipStream_t s) {
-    if (const char *e = getenv("SCS_AMD_SPMV_MAX_GRID")) {
+    if (const char *e = opt_get("spmv_max_grid")) {
       int g = atoi(e);
       if (g >= 1 && g <= SPMV_MAX_GRID) max_grid = g;
     }

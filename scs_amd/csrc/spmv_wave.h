@@ -277,7 +277,7 @@ struct WaveRowsDev {
   // barriers and no product staging pay even while the gathered vector still fits an XCD's L2
   static bool wanted(int cols, const eoff *hptr, int rows) {
     if (col_bits(cols) > 26) return false; // packed word: column bits + at least 6 row bits
-    if (const char *e = getenv("SCS_AMD_WAVEROWS")) return atoi(e) != 0; // tests force either path
+    if (const char *e = opt_get("waverows")) return atoi(e) != 0; // tests force either path
     return (long long)hptr[rows] >= 1000000LL;
   }
   // ---- layout construction, in three parts (round 5):
@@ -311,17 +311,17 @@ struct WaveRowsDev {
     sub_window_order = lockstep;
     ls_wpb = 16;
     ls_bmode = -1; // chosen below from the measured line sharing unless SCS_AMD_WR_LS_BARRIERS says otherwise
-    if (const char *e = getenv("SCS_AMD_WR_LOCKSTEP")) {
+    if (const char *e = opt_get("wr_lockstep")) {
       lockstep = atoi(e) == 1 ? 1 : 0;
       sub_window_order = atoi(e) != 0;
     }
-    if (const char *w = getenv("SCS_AMD_WR_LS_WPB")) ls_wpb = atoi(w) == 8 ? 8 : 16;
-    if (const char *b = getenv("SCS_AMD_WR_LS_BARRIERS")) ls_bmode = atoi(b) == 1 ? 1 : 4;
-    if (const char *o = getenv("SCS_AMD_WR_LS_ORDER")) sub_window_order = atoi(o) != 0; // measurements: lockstep without the quarter-window chunk order
+    if (const char *w = opt_get("wr_ls_wpb")) ls_wpb = atoi(w) == 8 ? 8 : 16;
+    if (const char *b = opt_get("wr_ls_barriers")) ls_bmode = atoi(b) == 1 ? 1 : 4;
+    if (const char *o = opt_get("wr_ls_order")) sub_window_order = atoi(o) != 0; // measurements: lockstep without the quarter-window chunk order
     if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
-    if (const char *e = getenv("SCS_AMD_WR_WPC")) wpc = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = opt_get("wr_wpc")) wpc = std::max(1, std::min(16, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
-    if (const char *e = getenv("SCS_AMD_WR_NNZ")) budget = std::max(64, atoi(e));
+    if (const char *e = opt_get("wr_nnz")) budget = std::max(64, atoi(e));
     auto partition = [&](long long bud) {
       ur.clear();
       ur.push_back(0);
@@ -342,7 +342,7 @@ struct WaveRowsDev {
     // greedy packing overshoots the resident wave count by a few units, which would cost a whole extra round
     // (measured: 513 workgroups on 512 slots 86 us vs 71 us): widen the budget until the units fit, unless
     // the row cap (packed word) is what limits them
-    if (!getenv("SCS_AMD_WR_NNZ"))
+    if (!opt_get("wr_nnz"))
       for (int tries = 0; (long long)ur.size() - 1 > (long long)wpc * cus && (long long)rows <= (long long)rows_cap * wpc * cus && tries < 60; ++tries) {
         budget += std::max<long long>(1, budget / 100);
         partition(budget);
@@ -372,7 +372,7 @@ struct WaveRowsDev {
   void finish(long long distinct) {
     lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
     pipelined = lines_per_entry < 0.8 ? 1 : 0;
-    if (const char *e = getenv("SCS_AMD_WR_PIPE")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
+    if (const char *e = opt_get("wr_pipe")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
     // lockstep: a barrier in front of every gather instruction when every gather is its own line, one per chunk when a unit's
     // gathers share lines anyway (band of 1024 rows at the headline sizes: 34.0 vs 35.3 us per product; uniformly random: 65.1 vs 62.2)
     if (ls_bmode < 0) ls_bmode = lines_per_entry < 0.3 ? 1 : 4;

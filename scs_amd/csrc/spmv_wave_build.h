@@ -172,7 +172,7 @@ inline bool wave_fill_dev(WaveRowsDev &w, const eoff *d_ptr, const int *d_idx, c
 inline void wave_build(WaveRowsDev &w, int rows, int cols, const eoff *hptr, const int *hidx, const real *hval, const CsrDev &mat,
                        hipStream_t st) {
   int mode = 1; // dev
-  if (const char *e = getenv("SCS_AMD_WR_BUILD")) mode = !strcmp(e, "host") ? 0 : (!strcmp(e, "verify") ? 2 : 1);
+  if (const char *e = opt_get("wr_build")) mode = !strcmp(e, "host") ? 0 : (!strcmp(e, "verify") ? 2 : 1);
   w.plan(rows, cols, hptr);
   w.alloc_and_upload_plan(st);
   long long distinct = 0;

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+# the suites force kernel variants and test hooks through SCS_AMD_* variables (monkeypatch.setenv): rows of class `ab` / `test` of
+# scs_amd/csrc/options.h are reachable from the environment only with this set
+os.environ["SCS_AMD_ALLOW_ENV_HOOKS"] = "1"
 
 
 def pytest_configure(config):

@@ -330,3 +330,122 @@ def test_measurement_forms_of_the_large_block_iteration_still_project(env, monke
     got = run()
     for a, b in zip(got, want):
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), (env, np.abs(a - b).max())
+
+
+# ---- round 6: the pipelined kernel's NB = 2 instantiation (every order 51..72) on hardware ----------------
+# psd_blocks_per_lane(npairs, 448) is 1 up to order 50 and 2 for every order 51..72 (from 51 the V-row groups no longer fit the 448
+# update lanes, from 59 neither do the blocks); 72 is the largest order whose three matrices fit the LDS.  None of these had been
+# compared with the reference on a GPU: the CPU restatement (tests/test_psd_step_host.py) loops lanes and cannot see the DPP lane
+# shifts, the register ties, the LDS ping-pong or the real barrier.
+def _bind_options(lib):
+    lib.scs_amd_set_option.restype = C.c_int
+    lib.scs_amd_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    return lib
+
+
+_NB2_CONES = [dict(s=[50, 51, 52, 58, 59, 64, 71, 72]),   # both sides of the NB 1 -> 2 switch, both reasons for NB = 2, odd orders (padding index), the LDS boundary
+              dict(cs=[26, 30, 36]),                      # Hermitian blocks through their real embeddings of order 52 / 60 / 72
+              dict(s=[72, 50, 7]),                        # one launch, blocks of different NB (the switch is per workgroup)
+              dict(l=4, q=[9], s=[63, 65, 2, 1], cs=[33, 1])]
+
+
+@pytest.mark.parametrize("cone", _NB2_CONES)
+def test_pipelined_psd_kernel_orders_51_to_72_match_reference_cold_and_warm(cone):
+    """Against the live reference's _scs_proj_dual_cone (LAPACK dsyevr / zheevr, src/cones.c:999-1155) at 1e-11: a cold projection,
+    then a 10-step drifting sequence warm started from the carried eigenbasis (large moves first, then the small ones warm starts are
+    for), then an unrelated input.  The same sequence through the two-phase step (option psd_pipe = 0) must agree with the pipelined
+    one to rounding: same rotations in the same order, the look-ahead's diagonal entries differ by O(eps |a|) only."""
+    ref = _ref_lib()
+    lib = _bind_options(_lib())
+    Tr = ref._scs_types
+    m = capi.cone_rows(cone)
+    kr = capi.make_cone(cone, Tr)
+    wr = ref._scs_init_cone(C.byref(kr), m)
+    assert wr
+    rng = np.random.default_rng(61)
+    seq = []
+    x0 = rng.standard_normal(m)
+    for rep in range(12):
+        if rep == 0:
+            pass
+        elif rep == 11:
+            x0 = 5.0 * rng.standard_normal(m)                          # unrelated: the carried basis is useless, not harmful
+        else:
+            x0 = x0 + (0.3 if rep < 4 else 1e-3) * rng.standard_normal(m)
+        seq.append(x0.copy())
+    want = []
+    for x in seq:
+        w = x.copy()
+        assert ref._scs_proj_dual_cone(w.ctypes.data_as(Tr.fp), wr, None, None) == 0
+        want.append(w)
+    ref._scs_finish_cone(wr)
+    got = {}
+    try:
+        for pipe in ("1", "0"):
+            assert lib.scs_amd_set_option(b"psd_pipe", pipe.encode()) == 0   # read by _scs_init_cone's device workspace
+            k = capi.make_cone(cone)
+            c = lib._scs_init_cone(C.byref(k), m)
+            assert c
+            res = []
+            for rep, x in enumerate(seq):
+                g = x.copy()
+                assert lib._scs_proj_dual_cone(g.ctypes.data_as(T.fp), c, None, None) == 0
+                err = np.abs(g - want[rep]).max() / max(1.0, np.abs(want[rep]).max())
+                assert err <= 1e-11, (cone, pipe, rep, err)
+                assert np.abs(g - x).max() > 1e-3
+                res.append(g)
+            got[pipe] = res
+            lib._scs_finish_cone(c)
+    finally:
+        lib.scs_amd_set_option(b"psd_pipe", None)
+    for rep, (a, b) in enumerate(zip(got["1"], got["0"])):
+        assert np.abs(a - b).max() <= 2e-12 * max(1.0, np.abs(b).max()), (cone, rep, np.abs(a - b).max())
+
+
+def test_pipelined_psd_kernel_every_order_from_2_to_72_against_numpy():
+    """Every order the pipelined instantiation handles, one launch each (so every order also appears as the launch's LARGEST block,
+    which sizes the LDS and the stride of the carried basis), cold and once warm, against numpy's eigh at 1e-11."""
+    from scs_amd import problems
+    lib = capi.load("libscsamd.so")
+    worst = 0.0
+    for k0 in range(2, 73):
+        cone = dict(s=[k0, max(1, k0 - 1)])
+        m = capi.cone_rows(cone)
+        k = capi.make_cone(cone)
+        w = lib.scs_amd_cone_init(C.byref(k), m, None)
+        assert w
+        x0 = np.random.default_rng(1000 + k0).standard_normal(m)
+        for rep in range(2):
+            x = x0 * (1.0 + 0.01 * rep)
+            want = problems.proj_dual_cone_np(x, cone)
+            got = x.copy()
+            assert lib.scs_amd_cone_proj_dual(w, got.ctypes.data_as(T.fp), None) == 0
+            err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+            assert err <= 1e-11, (k0, rep, err)
+            worst = max(worst, err)
+        lib.scs_amd_cone_finish(w)
+    assert worst <= 1e-11
+
+
+def test_pipelined_psd_kernel_fp32_orders_64_and_72():
+    """The -DSFLOAT build of the same instantiation (its threshold is the fp32 rounding floor of the rotations, cones.hip): orders
+    64 and 72 (+ the NB switch at 50 / 51) against the float64 numpy projection at fp32 accuracy, cold and over a warm sequence."""
+    from scs_amd import problems
+    lib = capi.load("libscsamd_f32.so")
+    T32 = capi.T32
+    cone = dict(s=[64, 72, 50, 51])
+    m = capi.cone_rows(cone)
+    k = capi.make_cone(cone, T32)
+    w = lib.scs_amd_cone_init(C.byref(k), m, None)
+    assert w
+    rng = np.random.default_rng(17)
+    v = rng.standard_normal(m)
+    for rep in range(6):
+        v = v + (0.3 if rep < 3 else 1e-3) * rng.standard_normal(m)
+        x = v.astype(np.float32)
+        want = problems.proj_dual_cone_np(x.astype(np.float64), cone)
+        assert lib.scs_amd_cone_proj_dual(w, x.ctypes.data_as(T32.fp), None) == 0
+        err = np.abs(x - want).max() / max(1.0, np.abs(want).max())
+        assert err <= 2e-4, (rep, err)
+        assert np.abs(x - v).max() > 1e-2
+    lib.scs_amd_cone_finish(w)

@@ -81,6 +81,34 @@ def test_config3_sdp_at_stated_shape_matches_reference_exact_cg():
     assert ra["stats"]["psd_unconverged"] == 0
 
 
+def test_sdp_with_blocks_of_order_51_to_72_matches_reference_exact_cg():
+    """Round 6: a whole solve whose PSD blocks all run the NB = 2 instantiation of the pipelined LDS kernel
+    (orders 64, 72, 59, 51 in one launch; warm started between ADMM iterations) against the reference (LAPACK dsyevr,
+    src/cones.c:999-1067) with exact linear solves on both sides: same iteration count and scale updates, 1e-6 on ScsInfo and x, y, s."""
+    ref = _ref("libscsindir_ref_exactcg.so")
+    amd = capi.load("libscsamd.so")
+    blocks = [64] * 24 + [72] * 6 + [59] * 6 + [51] * 4
+    bsize = 101
+    cone = dict(z=0, l=0, bu=np.ones(bsize - 1), bl=-np.ones(bsize - 1), bsize=bsize, q=[], s=blocks)
+    m = bsize + sum(k * (k + 1) // 2 for k in blocks)
+    pr = problems.random_cone_prob(1500, m, 10, cone, seed=64)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
+    kw = dict(verbose=0, acceleration_lookback=0)
+    ra = capi.solve(amd, prob, cg_tol_override=1e-12, want_stats=True, **kw)
+    rr = capi.solve(ref, prob, **kw)
+    ia, ir = ra["info"], rr["info"]
+    assert ia["status_val"] == ir["status_val"] == 1
+    assert ia["iter"] == ir["iter"], (ia["iter"], ir["iter"])
+    assert ia["scale_updates"] == ir["scale_updates"]
+    for k in ("pobj", "dobj", "res_pri", "res_dual", "scale"):
+        assert _rel(ia[k], ir[k]) <= REL, (k, ia[k], ir[k])
+    assert abs(ia["gap"] - ir["gap"]) <= REL * max(1.0, abs(ir["pobj"]), abs(ir["dobj"])), (ia["gap"], ir["gap"])
+    for v in ("x", "y", "s"):
+        d = np.abs(ra[v] - rr[v]).max() / max(1.0, np.abs(rr[v]).max())
+        assert d <= REL, (v, d)
+    assert ra["stats"]["psd_unconverged"] == 0
+
+
 def test_fp32_at_1e5_against_fp32_reference_and_known_optimum(monkeypatch):
     """fp32 at n = 1e5 (the reference's SFLOAT build needs ~0.8 s per ADMM iteration at this size, so the
     reference leg is capped): (i) after the same 60 iterations both fp32 trajectories -- inexact CG in fp32,
