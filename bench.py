@@ -66,9 +66,11 @@ def _pick(d, keys):
 def compact_line(out, detail_file):
     roof = _pick(out.get("roofline") or {}, ("bound", "achieved", "peak", "unit", "frac", "frac_profiled", "traffic", "avg_launch_us",
                                               "algorithmic_bytes_per_launch", "launches_timed", "traffic_static"))
-    roof["kernel"] = "csr_wave_lockstep_kernel (CSR SpMV, A and A', scs_amd/csrc/spmv_wave.h)"
-    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                       "dtype", "data"))
+    roof["kernel"] = str((out.get("roofline") or {}).get("kernel_short") or (out.get("roofline") or {}).get("kernel") or "")[:120]
+    line = _pick(out, ("metric", "value", "value_definition", "ms_per_iter_whole_solve", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                       "ms_per_step_definition", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "iters_to_eps_spread"))
+    if "value_definition" in line:
+        line["value_definition"] = line["value_definition"][:120]
     cfg = out.get("config") or {}
     line["config"] = dict(_pick(cfg, ("n", "m", "nnz", "problems_per_gpu")), workload=str(cfg.get("workload", ""))[:160])
     line["roofline"] = roof
@@ -92,11 +94,11 @@ def compact_line(out, detail_file):
     pw = out.get("parity_window")
     if isinstance(pw, dict):
         line["parity_window"] = dict(rows=pw.get("rows"), max_rel_diff=pw.get("max_rel_diff"),
-                                     max_rel_diff_by_iter=[max(v for k, v in r.items() if k != "iter" and isinstance(v, float))
+                                     max_rel_diff_by_iter=[max((v for k, v in r.items() if k != "iter" and isinstance(v, float)), default=None)
                                                            for r in pw.get("rel_diff_per_iter", [])])
     b = out.get("batch")
     if isinstance(b, dict):
-        lb = _pick(b, ("problems", "wall_s", "problems_per_s", "admm_iters_per_s", "all_solved", "error"))
+        lb = _pick(b, ("problems", "problems_per_gpu", "ranks", "iters_sum", "wall_s", "problems_per_s", "admm_iters_per_s", "all_solved", "error"))
         if isinstance(b.get("parity"), dict):
             lb["parity"] = _pick(b["parity"], ("ok", "same_status", "iter_ratio", "pobj_rel_diff", "dobj_rel_diff"))
         line["batch"] = lb
@@ -111,6 +113,9 @@ def compact_line(out, detail_file):
                                          for c in sec["psd_large_blocks"].get("cases", [])}
         if isinstance(sec.get("headline_aa_on"), dict):
             ls["headline_aa_on"] = _pick(sec["headline_aa_on"], ("status", "iters_to_eps", "time_to_eps_s", "value_it_per_s", "error"))
+        if isinstance(sec.get("headline_many_small_soc"), dict):
+            ls["headline_many_small_soc"] = _pick(sec["headline_many_small_soc"], ("status", "q", "soc_cones", "iters_to_eps", "time_to_eps_s",
+                                                                                  "value_it_per_s", "cone_us_per_projection", "error"))
         if isinstance(sec.get("configs4_fp32"), dict):
             ls["configs4_fp32"] = _pick(sec["configs4_fp32"], ("status", "iters_to_eps", "time_to_eps_s", "value_it_per_s", "window_it_per_s",
                                                               "spmv_avg_launch_us", "spmv_frac_of_8TBs", "error"))
@@ -530,6 +535,15 @@ class HipSolver:
         return dict(renumbered=bool(out[0]), lines_per_entry_given=[out[1], out[2]], lines_per_entry_used=[out[3], out[4]] if out[0] else [out[1], out[2]],
                     decide_s=out[5])
 
+    def spmv_kernels(self):
+        """the SpMV kernel scs_init chose for A / A' (template names as rocprofv3 lists them)"""
+        names = []
+        for which in (0, 1):
+            buf = C.create_string_buffer(96)
+            self.lib.scs_amd_get_spmv_kernel_name(self.w, which, buf, 96)
+            names.append(buf.value.decode())
+        return names
+
     def stats(self):
         s = self.T.ScsAmdStats()
         self.lib.scs_amd_get_stats(self.w, C.byref(s))
@@ -571,6 +585,9 @@ class StubSolver:
     def stats(self):
         return dict(cg_iters=10 * self.it, spmv_launches=0, spmv_ms=0.0, spmv_bytes=0, cone_ms=0.0, cone_projs=0)
 
+    def spmv_kernels(self):
+        return ["stub", "stub"]
+
     def profiling(self, on):
         pass
 
@@ -599,25 +616,31 @@ def respawn(args):
 
 
 # ---------------------------------------------------------------------------------------------------
-def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev):
+def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev, stub=False):
     """BASELINE configs[3]: independent n=2e5 SOCPs, `batch_per_gpu` per GPU (problem j -> rank j % world),
     `batch_concurrency` host threads per GPU each driving its own ScsWork / HIP stream; RCCL carries the
     descriptor (broadcast) and the result records (all-gather): scs_amd/batch.py."""
     from concurrent.futures import ThreadPoolExecutor
-    from scs_amd import batch, capi, problems
-    lib = capi.load(lib_name)
+    from scs_amd import batch
+    if not stub:
+        from scs_amd import capi, problems
+        lib = capi.load(lib_name)
     count = args.batch_per_gpu * world
     desc = batch.broadcast_descriptor(dict(n=args.batch_n, m=2 * args.batch_n, col_nnz=args.col_nnz, seed=1000, count=count,
                                            aa=0, max_iters=args.max_iters), dist, dev)
     mine = batch.partition(desc["count"], world, rank)
     probs = {}
-    for j in mine:  # generation is not part of the timed region
+    for j in ([] if stub else mine):  # generation is not part of the timed region
         pr = problems.random_socp(desc["n"], desc["m"], desc["col_nnz"], seed=desc["seed"] + j)
         probs[j] = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"])
 
     kept = {}
 
     def solve_one(j):
+        if stub:  # launch-path self test: the partition, the thread pool, the barriers and the record all-gather without a GPU
+            its = 25 * (1 + j % 3)
+            time.sleep(0.0005 * its)
+            return (j, 1, its, float(j), float(j), 0.0, 0.0, 0.0, 0.5 * its)
         lib.scs_amd_set_device(local_rank)
         r = capi.solve(lib, probs[j], verbose=0, acceleration_lookback=0, max_iters=desc["max_iters"])
         i = r["info"]
@@ -628,11 +651,13 @@ def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev):
 
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    if not stub:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=max(1, args.batch_concurrency)) as ex:
         recs = list(ex.map(solve_one, mine))
-    torch.cuda.synchronize()
+    if not stub:
+        torch.cuda.synchronize()
     if dist:
         dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
@@ -642,7 +667,8 @@ def batch_workload(args, lib_name, rank, world, local_rank, dist, torch, dev):
     wall = float(el.item())
     out = dict(workload=f"BASELINE configs[3]: {count} independent random SOCPs n={desc['n']} m={desc['m']}, {args.batch_per_gpu} per GPU, "
                         f"{args.batch_concurrency} host threads per GPU, setup (scs_init) inside the timed region",
-               problems=count, wall_s=wall, problems_per_s=count / wall, admm_iters_per_s=float(np.nansum(tab[:, 2])) / wall,
+               problems=count, problems_per_gpu=args.batch_per_gpu, ranks=world, problems_solved_by_rank=len(mine), wall_s=wall, problems_per_s=count / wall,
+               iters_sum=float(np.nansum(tab[:, 2])), admm_iters_per_s=float(np.nansum(tab[:, 2])) / wall,
                all_solved=bool(np.all(tab[:, 1] == 1)), iters_min_max=[int(np.nanmin(tab[:, 2])), int(np.nanmax(tab[:, 2]))])
     if 0 in kept:  # judged on the host in the manner of test/problem_utils.h:107-249 (scs_amd/verify.py), outside the timed region
         from scs_amd import verify
@@ -731,6 +757,38 @@ def secondary_single_gpu(args, headline_prob=None):
         s.close()
     except Exception as e:
         out["headline_aa_on"] = dict(error=repr(e))
+    # ---- "also report a many-small-SOC variant, e.g. q_i = 8" of the headline (cone recipe
+    # test/random_socp_prob.c:83-107 with every second-order cone of size 8: 150 000 cones -> k_soc_tiny, one lane per cone)
+    try:
+        q8 = 8
+        s = HipSolver(args, 0, 0, args.n, 2 * args.n, args.col_nnz, args.seed, 0, 1e-4, q_fixed=q8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.begin()
+        s.steps(25)
+        st0 = s.stats()
+        s.profiling(True)
+        s.steps(25)
+        st1 = s.stats()
+        s.profiling(False)
+        while not s.converged():
+            if s.steps(100) >= s.max_iters:
+                break
+        torch.cuda.synchronize()
+        t_eps = time.perf_counter() - t0
+        res = s.end()
+        ncp, cms = st1["cone_projs"] - st0["cone_projs"], st1["cone_ms"] - st0["cone_ms"]
+        out["headline_many_small_soc"] = dict(
+            workload=f"the headline sizes and data law (random SOCP n={args.n} m={2*args.n} nnz={args.n*args.col_nnz}) with every second-order cone "
+                     f"of size {q8} (test/random_socp_prob.c:83-107's split of the rows, q_i fixed): whole solve to eps=1e-4",
+            q=q8, soc_cones=len(s.cone["q"]), status=res["status"], iters_to_eps=res["iter"] if res["status_val"] == 1 else None, iters=res["iter"],
+            time_to_eps_s=t_eps if res["status_val"] == 1 else None, value_it_per_s=res["iter"] / t_eps,
+            cone_us_per_projection=(1e3 * cms / ncp) if ncp > 0 else None, cone_projections_timed=int(ncp),
+            cone_kernels="k_zero_pos + k_soc_tiny (one lane per cone) between k_moreau_pre / k_moreau_post, HIP events around the whole projection",
+            final={k: res[k] for k in ("pobj", "dobj", "res_pri", "res_dual", "gap")})
+        s.close()
+    except Exception as e:
+        out["headline_many_small_soc"] = dict(error=repr(e))
     # ---- configs[4]: fp32 n=4e6: windowed rate + SpMV bandwidth, then the SAME solve carried to eps = 1e-3
     try:
         n4 = args.fp32_n
@@ -944,6 +1002,7 @@ def main():
         torch.cuda.synchronize()
     solve_wall = time.perf_counter() - t_solve0  # includes the two window barriers (microseconds)
     stats2 = S.stats()
+    spmv_kernel_names = S.spmv_kernels()
     res = S.end()
 
     red = torch.tensor([elapsed, solve_wall], dtype=torch.float64, device=dev)
@@ -1006,9 +1065,9 @@ def main():
         cpu1 = _cpu_start(cpu_spec(args, n, 1))  # ran side by side measured 30 % low, and slowed the batch workload's host threads)
 
     batch_out = None
-    if not stub and args.secondary != "none" and args.dtype == "f64":
+    if args.secondary != "none" and args.dtype == "f64":
         try:
-            batch_out = batch_workload(args, "libscsamd.so", rank, world, local_rank, dist, torch, dev)
+            batch_out = batch_workload(args, "libscsamd.so", rank, world, local_rank, dist, torch, dev, stub=stub)
         except Exception as e:
             batch_out = dict(error=str(e))
 
@@ -1017,9 +1076,12 @@ def main():
         spmv_samples = stats1["spmv_launches"] - stats0["spmv_launches"]
         spmv_ms = stats1["spmv_ms"] - stats0["spmv_ms"]
         bytes_per_spmv = stats1["spmv_bytes"] / 2.0  # already computed with sizeof(scs_float) of the library
+        kn = spmv_kernel_names
         roof = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                    kernel="csr_wave_lockstep_kernel / csr_wave_kernel (wave-owned rows CSR SpMV, both orientations; the library picks the lockstep "
-                           "instantiation for fp64 systems from 5e6 nonzeros on, profiles/r4_spmv_lockstep.md)")
+                    kernel_short=(kn[0] if kn[0] == kn[1] else "A: %s, A': %s" % tuple(kn)) + " (CSR SpMV, A and A')",
+                    kernel="%s for A, %s for A' (as chosen by scs_init for this matrix: scs_amd_get_spmv_kernel_name; wave-owned-rows layout from 1e6 "
+                           "nonzeros on, its lockstep instantiation for fp64 systems from 5e6 on, scs_amd/csrc/spmv_wave.h; CSR-stream kernel below, "
+                           "spmv.h)" % tuple(kn))
         if spmv_samples > 0 and spmv_ms > 0:
             avg_s = spmv_ms / spmv_samples * 1e-3
             roof["achieved"] = bytes_per_spmv / avg_s / 1e9
@@ -1043,8 +1105,14 @@ def main():
         out = {
             "metric": "ADMM iters/sec (+ time-to-eps=1e-4), 1e6-var random SOCP, 1 GPU" if not stub else "stub (launch-path self test)",
             "value": total_iters / solve_wall_max,
-            "value_definition": "ADMM iterations of the whole solve to eps (sum over ranks) / wall time of that solve (max over "
-                                "ranks): SURVEY 8(d) info.iter / solve_time",
+            "value_definition": "whole solve to eps: sum of ranks' ADMM iterations / max wall time (info.iter / solve_time, SURVEY 8d)",
+            "ms_per_iter_whole_solve": 1e3 * solve_wall_max / max(total_iters, 1),  # = 1000 / value
+            "ms_per_step_definition": "iterations warmup..warmup+steps ONLY (early iterations run several times the CG its of the average one); 1000/value is ms_per_iter_whole_solve",
+            # the default inexact-CG schedule makes the iteration count to eps a function of summation order: what has been
+            # observed for THIS problem across builds / orders of summation / AA and by the reference itself -- +-10 % of `value` is trajectory noise
+            "iters_to_eps_spread": ({"observed": [475, 525, 575], "reference_cpu": 575, "this_run": res["iter"], "step": 25,
+                                     "source": "BENCH_r02..r05, profiles/r5_term_parity_n1e6.json"}
+                                    if (n == 1000000 and m == 2000000 and col_nnz == 10 and args.dtype == "f64" and not args.q_fixed and not stub) else None),
             "unit": "ADMM iters/sec",
             "n_gpus": world,
             "rccl_ranks_seen": ranks_seen,

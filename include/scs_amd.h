@@ -301,6 +301,9 @@ void scs_amd_get_reorder_info(const ScsWork *w, double *out);
 /* how scs_init laid out A (out[0..2]) and A' (out[3..5]): wave-owned-rows layout built (0 / 1), built on the device (0 / 1),
  * distinct 128-byte lines per gathered entry (scs_amd/csrc/spmv_wave.h, spmv_wave_build.h) */
 void scs_amd_get_layout_info(const ScsWork *w, double *out);
+/* the SpMV kernel scs_init chose for A (which = 0) / A' (which = 1): the template's name as rocprofv3 lists it, e.g.
+ * "csr_wave_lockstep_kernel<EPI,16,4>", "csr_wave_kernel<EPI,0>", "csr_stream_kernel<EPI>".  Returns the length needed. */
+scs_int scs_amd_get_spmv_kernel_name(const ScsWork *w, scs_int which, char *buf, scs_int cap);
 /* Test hook, host code only: the renumbering decision scs_init would take for this matrix and cone (no device needed).
  * col_new2old (n) and row_new2old (m) receive new index -> caller's index (identity when nothing is kept); info (6 doubles, may be
  * NULL) as scs_amd_get_reorder_info.  Returns 1 if a renumbering is kept, 0 if not, < 0 on error. */

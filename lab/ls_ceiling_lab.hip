@@ -142,7 +142,7 @@ int main(int argc, char **argv) {
   for (int i = 0; i < m; ++i) rp[i + 1] += rp[i];
   { std::vector<int> nx(rp.begin(), rp.end() - 1);
     for (int j = 0; j < n; ++j) for (int k = cp[j]; k < cp[j + 1]; ++k) { const int q = nx[ci[k]]++; rj[q] = j; rx[q] = cx[k]; } }
-  setenv("SCS_AMD_WR_LOCKSTEP", "1", 1);
+  opt_set("wr_lockstep", "1");
   Mat A, At;
   build(A, m, n, rp, rj, rx, st);   // rows of A gather from an n-vector
   build(At, n, m, cp, ci, cx, st);  // rows of A' gather from an m-vector

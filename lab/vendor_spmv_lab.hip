@@ -1,0 +1,323 @@
+// vendor_spmv_lab.hip -- an OUTSIDE yardstick for the SpMV ceiling (VERDICT r5 missing 4 / next 2).  LAB ONLY: the product links no vendor
+// sparse library and this file is not part of it.
+//
+// The reference's GPU backend multiplies with cusparseSpMV CSR_ALG1 (linsys/gpu/gpu.c:14-28, gpu.h:77).  Its ROCm counterpart is
+// rocsparse_spmv on a CSR descriptor; here the SAME matrix (BASELINE's random-SOCP law: n columns with 10 uniformly random rows each out of
+// m = 2n) goes, in both orientations, through
+//     rocSPARSE  csr adaptive / rowsplit ("stream") / LRB / nnzsplit / default   (analysis = preprocess stage, excluded from the timing)
+// and, in the same process, through this library's product kernels by way of its B1 plugin ABI on device pointers
+//     scs_amd_linsys_mul_a_dev / _mul_at_dev   (options wr_lockstep = 1 | 0, waverows = 0: lockstep, plain wave kernel, CSR-stream kernel)
+// fp64 / int32 at n = 1e6 (headline) and n = 2e5 (configs[3]'s size), fp32 at n = 4e6 (configs[4]).  30 reps, HIP events on the stream
+// rocSPARSE runs on; the library's figure is its own HIP-event sampling (every launch's stream is private) cross-checked by wall clock
+// over back-to-back launches.
+//
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-deprecated-declarations lab/vendor_spmv_lab.hip -o lab/vendor_spmv_lab -lrocsparse -ldl
+// run  : lab/vendor_spmv_lab [cases: n:f64|f32,...] [--only-vendor alg]   (from the repository root: it dlopens scs_amd/lib/*.so)
+#include <hip/hip_runtime.h>
+#include <rocsparse/rocsparse.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                       \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                      \
+    }                                                                               \
+  } while (0)
+#define RS(x)                                                                   \
+  do {                                                                          \
+    rocsparse_status s_ = (x);                                                  \
+    if (s_ != rocsparse_status_success) {                                       \
+      fprintf(stderr, "rocsparse status %d at %s:%d\n", (int)s_, __FILE__, __LINE__); \
+      exit(3);                                                                  \
+    }                                                                           \
+  } while (0)
+
+template <class F>
+struct ScsMatrixT { // include/scs.h:41-56 (CSC)
+  F *x;
+  int *i, *p;
+  int m, n;
+};
+struct Stats { // include/scs_amd.h ScsAmdStats
+  long long cg_iters, lin_sys_solves, mat_vecs, spmv_launches;
+  double spmv_ms, cg_ms, cone_ms;
+  long long cone_projs, nnz, spmv_bytes, psd_unconverged;
+};
+
+template <class F>
+struct Lib {
+  void *h = nullptr;
+  void *(*init)(const ScsMatrixT<F> *, const ScsMatrixT<F> *, const F *) = nullptr;
+  void (*fin)(void *) = nullptr;
+  int (*mul_a)(void *, const F *, F *) = nullptr;
+  int (*mul_at)(void *, const F *, F *) = nullptr;
+  int (*sync)(void *) = nullptr;
+  int (*set_opt)(const char *, const char *) = nullptr;
+  void (*prof)(void *, int) = nullptr;
+  void (*stats)(const void *, Stats *) = nullptr;
+  bool open(const char *path) {
+    h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      fprintf(stderr, "dlopen %s: %s\n", path, dlerror());
+      return false;
+    }
+    init = (decltype(init))dlsym(h, "scs_init_lin_sys_work");
+    fin = (decltype(fin))dlsym(h, "scs_free_lin_sys_work");
+    mul_a = (decltype(mul_a))dlsym(h, "scs_amd_linsys_mul_a_dev");
+    mul_at = (decltype(mul_at))dlsym(h, "scs_amd_linsys_mul_at_dev");
+    sync = (decltype(sync))dlsym(h, "scs_amd_linsys_sync");
+    set_opt = (decltype(set_opt))dlsym(h, "scs_amd_set_option");
+    prof = (decltype(prof))dlsym(h, "scs_amd_linsys_set_profiling");
+    stats = (decltype(stats))dlsym(h, "scs_amd_linsys_get_stats");
+    return init && fin && mul_a && mul_at && sync && set_opt && prof && stats;
+  }
+};
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Row {
+  std::string name;
+  double us_a, us_at; // y = A x (rows m gather from n), x = A' y (rows n gather from m)
+};
+
+template <class F>
+static void run_case(int n, const char *libpath, const char *only_vendor) {
+  const int m = 2 * n, cn = 10;
+  const size_t nnz = (size_t)n * cn;
+  const bool f64 = sizeof(F) == 8;
+  printf("\n## n = %d, m = %d, nnz = %zu, %s / int32\n\n", n, m, nnz, f64 ? "fp64" : "fp32");
+  // CSC(A): 10 distinct uniformly random sorted rows per column (test/problem_utils.h:64-79's law), values U[-1, 1]
+  std::mt19937_64 rng(1234);
+  std::vector<int> cp(n + 1), ci(nnz);
+  std::vector<F> cx(nnz);
+  std::uniform_int_distribution<int> ur(0, m - 1);
+  std::uniform_real_distribution<double> uv(-1, 1);
+  for (int j = 0; j < n; ++j) {
+    cp[j] = j * cn;
+    int *r = &ci[(size_t)j * cn];
+    for (int k = 0; k < cn; ++k) r[k] = ur(rng);
+    std::sort(r, r + cn);
+    for (int k = 1; k < cn; ++k)
+      if (r[k] <= r[k - 1]) r[k] = std::min(m - 1, r[k - 1] + 1);
+    for (int k = 0; k < cn; ++k) cx[(size_t)j * cn + k] = (F)uv(rng);
+  }
+  cp[n] = (int)nnz;
+  // CSR(A) = transpose, rows sorted by column
+  std::vector<int> rp(m + 1, 0), rj(nnz);
+  std::vector<F> rx(nnz);
+  for (int v : ci) rp[v + 1]++;
+  for (int i = 0; i < m; ++i) rp[i + 1] += rp[i];
+  {
+    std::vector<int> nx(rp.begin(), rp.end() - 1);
+    for (int j = 0; j < n; ++j)
+      for (int k = cp[j]; k < cp[j + 1]; ++k) {
+        const int q = nx[ci[k]]++;
+        rj[q] = j;
+        rx[q] = cx[k];
+      }
+  }
+  std::vector<F> hx(n), hy(m);
+  for (auto &v : hx) v = (F)uv(rng);
+  for (auto &v : hy) v = (F)uv(rng);
+  // reference products on the host (double accumulation)
+  std::vector<double> want_a(m, 0.0), want_at(n, 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int k = cp[j]; k < cp[j + 1]; ++k) {
+      want_a[ci[k]] += (double)cx[k] * hx[j];
+      want_at[j] += (double)cx[k] * hy[ci[k]];
+    }
+  auto dev = [](const void *h, size_t bytes) {
+    void *d;
+    CK(hipMalloc(&d, bytes));
+    CK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    return d;
+  };
+  int *d_rp = (int *)dev(rp.data(), (m + 1) * 4), *d_rj = (int *)dev(rj.data(), nnz * 4);
+  int *d_cp = (int *)dev(cp.data(), (n + 1) * 4), *d_ci = (int *)dev(ci.data(), nnz * 4);
+  F *d_rx = (F *)dev(rx.data(), nnz * sizeof(F)), *d_cx = (F *)dev(cx.data(), nnz * sizeof(F));
+  F *d_xn = (F *)dev(hx.data(), n * sizeof(F)), *d_ym = (F *)dev(hy.data(), m * sizeof(F));
+  F *d_outm, *d_outn;
+  CK(hipMalloc(&d_outm, m * sizeof(F)));
+  CK(hipMalloc(&d_outn, n * sizeof(F)));
+  auto check = [&](const char *what, F *d, const std::vector<double> &want) {
+    std::vector<F> h(want.size());
+    CK(hipMemcpy(h.data(), d, want.size() * sizeof(F), hipMemcpyDeviceToHost));
+    double worst = 0, scale = 1;
+    for (size_t i = 0; i < want.size(); ++i) {
+      worst = std::max(worst, std::abs((double)h[i] - want[i]));
+      scale = std::max(scale, std::abs(want[i]));
+    }
+    const double tol = f64 ? 1e-12 : 2e-5;
+    if (worst > tol * scale) {
+      printf("!! %s: product differs from the host product by %.3e of scale\n", what, worst / scale);
+      return false;
+    }
+    return true;
+  };
+  const double bytes_a = (double)nnz * (sizeof(F) + 4) + 4.0 * (m + 1) + (double)sizeof(F) * n + (double)sizeof(F) * m;
+  const double bytes_at = (double)nnz * (sizeof(F) + 4) + 4.0 * (n + 1) + (double)sizeof(F) * m + (double)sizeof(F) * n;
+  std::vector<Row> rows;
+  const int reps = 30;
+
+  // ---------------- rocSPARSE ----------------
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  rocsparse_handle hd;
+  RS(rocsparse_create_handle(&hd));
+  RS(rocsparse_set_stream(hd, st));
+  const rocsparse_datatype dt = f64 ? rocsparse_datatype_f64_r : rocsparse_datatype_f32_r;
+  rocsparse_spmat_descr mA, mAt;
+  RS(rocsparse_create_csr_descr(&mA, m, n, nnz, d_rp, d_rj, d_rx, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, dt));
+  RS(rocsparse_create_csr_descr(&mAt, n, m, nnz, d_cp, d_ci, d_cx, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, dt));
+  rocsparse_dnvec_descr vxn, vym, vom, von;
+  RS(rocsparse_create_dnvec_descr(&vxn, n, d_xn, dt));
+  RS(rocsparse_create_dnvec_descr(&vym, m, d_ym, dt));
+  RS(rocsparse_create_dnvec_descr(&vom, m, d_outm, dt));
+  RS(rocsparse_create_dnvec_descr(&von, n, d_outn, dt));
+  struct Alg {
+    const char *name;
+    rocsparse_spmv_alg alg;
+  } algs[] = {{"rocsparse csr adaptive", rocsparse_spmv_alg_csr_adaptive},
+              {"rocsparse csr rowsplit (\"stream\")", rocsparse_spmv_alg_csr_rowsplit},
+              {"rocsparse csr lrb", rocsparse_spmv_alg_csr_lrb},
+              {"rocsparse csr nnzsplit", rocsparse_spmv_alg_csr_nnzsplit},
+              {"rocsparse default", rocsparse_spmv_alg_default}};
+  const F alpha = 1, beta = 0;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (const Alg &al : algs) {
+    if (only_vendor && !strstr(al.name, only_vendor)) continue;
+    double us[2];
+    bool ok = true;
+    for (int o = 0; o < 2; ++o) {
+      rocsparse_spmat_descr M = o ? mAt : mA;
+      rocsparse_dnvec_descr X = o ? vym : vxn, Y = o ? von : vom;
+      // a fresh descriptor per algorithm would be cleaner; the analysis data of one algorithm is not reused by another
+      size_t bs = 0;
+      void *buf = nullptr;
+      rocsparse_status s = rocsparse_spmv(hd, rocsparse_operation_none, &alpha, M, X, &beta, Y, dt, al.alg, rocsparse_spmv_stage_buffer_size, &bs, nullptr);
+      if (s != rocsparse_status_success) {
+        ok = false;
+        break;
+      }
+      CK(hipMalloc(&buf, bs ? bs : 16));
+      const double t0 = now_s();
+      s = rocsparse_spmv(hd, rocsparse_operation_none, &alpha, M, X, &beta, Y, dt, al.alg, rocsparse_spmv_stage_preprocess, &bs, buf);
+      CK(hipStreamSynchronize(st));
+      const double t_pre = now_s() - t0;
+      if (s != rocsparse_status_success) {
+        ok = false;
+        break;
+      }
+      for (int r = 0; r < 3; ++r) RS(rocsparse_spmv(hd, rocsparse_operation_none, &alpha, M, X, &beta, Y, dt, al.alg, rocsparse_spmv_stage_compute, &bs, buf));
+      CK(hipStreamSynchronize(st));
+      double tot = 0;
+      for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0, st));
+        RS(rocsparse_spmv(hd, rocsparse_operation_none, &alpha, M, X, &beta, Y, dt, al.alg, rocsparse_spmv_stage_compute, &bs, buf));
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+      }
+      us[o] = 1e3 * tot / reps;
+      ok = ok && check(al.name, o ? d_outn : d_outm, o ? want_at : want_a);
+      printf("   (%s, %s: analysis %.1f ms, buffer %zu B)\n", al.name, o ? "A'" : "A", 1e3 * t_pre, bs);
+      CK(hipFree(buf));
+    }
+    if (ok) rows.push_back({al.name, us[0], us[1]});
+    else printf("   (%s: not available for this matrix / build)\n", al.name);
+  }
+  RS(rocsparse_destroy_handle(hd));
+
+  // ---------------- this library, through its B1 ABI on device pointers ----------------
+  if (!only_vendor) {
+    Lib<F> L;
+    if (!L.open(libpath)) exit(4);
+    ScsMatrixT<F> A{cx.data(), ci.data(), cp.data(), m, n};
+    std::vector<F> diag_r((size_t)n + m, (F)1);
+    struct Mode {
+      const char *name;
+      const char *lockstep, *waverows;
+    } modes[] = {{"scs_amd: the library's own choice", nullptr, nullptr},
+                 {"scs_amd csr_wave_lockstep_kernel<PLAIN,16,4> (forced)", "1", "1"},
+                 {"scs_amd csr_wave_kernel (plain wave-owned rows, forced)", "0", "1"},
+                 {"scs_amd csr_stream_kernel (forced)", nullptr, "0"}};
+    for (const Mode &md : modes) {
+      L.set_opt("wr_lockstep", md.lockstep);
+      L.set_opt("waverows", md.waverows);
+      void *w = L.init(&A, nullptr, diag_r.data());
+      if (!w) {
+        printf("   (%s: init failed)\n", md.name);
+        continue;
+      }
+      CK(hipDeviceSynchronize());
+      double us[2], wall[2];
+      bool ok = true;
+      for (int o = 0; o < 2; ++o) {
+        auto go = [&]() { return o ? L.mul_at(w, d_ym, d_outn) : L.mul_a(w, d_xn, d_outm); };
+        for (int r = 0; r < 3; ++r) go();
+        L.sync(w);
+        L.prof(w, 1);
+        Stats s0, s1;
+        L.stats(w, &s0);
+        const double t0 = now_s();
+        for (int r = 0; r < 8 * reps; ++r) go(); // every 8th launch is event-timed
+        L.sync(w);
+        wall[o] = 1e6 * (now_s() - t0) / (8 * reps);
+        L.stats(w, &s1);
+        L.prof(w, 0);
+        us[o] = 1e3 * (s1.spmv_ms - s0.spmv_ms) / std::max<long long>(1, s1.spmv_launches - s0.spmv_launches);
+        ok = ok && check(md.name, o ? d_outn : d_outm, o ? want_at : want_a);
+      }
+      if (ok) {
+        rows.push_back({md.name, us[0], us[1]});
+        printf("   (%s: wall clock per back-to-back launch %.1f / %.1f us)\n", md.name, wall[0], wall[1]);
+      }
+      L.fin(w);
+    }
+    L.set_opt("wr_lockstep", nullptr);
+    L.set_opt("waverows", nullptr);
+  }
+  printf("\n| kernel | y = A x (us) | x = A' y (us) | mean (us) | of 8 TB/s (algorithmic %.0f / %.0f MB) | ns per nonzero |\n|---|---|---|---|---|---|\n", bytes_a / 1e6,
+         bytes_at / 1e6);
+  for (const Row &r : rows) {
+    const double mean = 0.5 * (r.us_a + r.us_at);
+    printf("| %s | %.1f | %.1f | %.1f | %.3f | %.2f |\n", r.name.c_str(), r.us_a, r.us_at, mean, 0.5 * (bytes_a + bytes_at) / (mean * 1e-6) / 8e12, 1e3 * mean / (double)nnz);
+  }
+  fflush(stdout);
+  for (void *p : {(void *)d_rp, (void *)d_rj, (void *)d_cp, (void *)d_ci, (void *)d_rx, (void *)d_cx, (void *)d_xn, (void *)d_ym, (void *)d_outm, (void *)d_outn}) CK(hipFree(p));
+}
+
+int main(int argc, char **argv) {
+  std::string cases = "1000000:f64,200000:f64,4000000:f32";
+  const char *only_vendor = nullptr;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--only-vendor") && i + 1 < argc) only_vendor = argv[++i];
+    else cases = argv[i];
+  }
+  printf("# SpMV on BASELINE's random-SOCP matrix: rocSPARSE csrmv beside this library's kernels, one process, one MI355X\n");
+  size_t pos = 0;
+  while (pos < cases.size()) {
+    size_t q = cases.find(',', pos);
+    if (q == std::string::npos) q = cases.size();
+    const std::string c = cases.substr(pos, q - pos);
+    pos = q + 1;
+    const int n = atoi(c.c_str());
+    if (c.find("f32") != std::string::npos) run_case<float>(n, "scs_amd/lib/libscsamd_f32.so", only_vendor);
+    else run_case<double>(n, "scs_amd/lib/libscsamd_linsys.so", only_vendor);
+  }
+  return 0;
+}

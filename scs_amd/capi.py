@@ -203,6 +203,8 @@ def bind_api(lib, T, full=True, linsys=True, cones=True, stats=True):
             lib.scs_amd_get_reorder_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
             lib.scs_amd_get_layout_info.restype = None
             lib.scs_amd_get_layout_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+            lib.scs_amd_get_spmv_kernel_name.restype = scs_int
+            lib.scs_amd_get_spmv_kernel_name.argtypes = [C.c_void_p, scs_int, C.c_char_p, scs_int]
             lib.scs_amd_set_residuals_every_iter.restype = None
             lib.scs_amd_set_residuals_every_iter.argtypes = [C.c_void_p, scs_int]
     lib._scs_types = T

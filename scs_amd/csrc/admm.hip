@@ -1531,6 +1531,24 @@ void scs_amd_get_layout_info(const ScsWork *w, double *out) {
   }
 }
 
+// which SpMV kernel scs_init chose for A (which = 0) / A' (which = 1), as the template instantiation's name (what rocprofv3 lists):
+// bench.py labels its roofline block with it (the label was hard-coded).  Returns the length needed.
+scs_int scs_amd_get_spmv_kernel_name(const ScsWork *w, scs_int which, char *buf, scs_int cap) {
+  if (!w) return -1;
+  const WaveRowsDev *wv = which ? w->ls.At.wave : w->ls.A.wave;
+  char tmp[96];
+  if (wv && wv->built && wv->lockstep) snprintf(tmp, sizeof tmp, "csr_wave_lockstep_kernel<EPI,%d,%d>", wv->ls_wpb, wv->ls_bmode);
+  else if (wv && wv->built) snprintf(tmp, sizeof tmp, "csr_wave_kernel<EPI,%d>", wv->pipelined);
+  else snprintf(tmp, sizeof tmp, "csr_stream_kernel<EPI>");
+  const size_t len = strlen(tmp);
+  if (buf && cap > 0) {
+    const size_t c = std::min(len, (size_t)cap - 1);
+    memcpy(buf, tmp, c);
+    buf[c] = 0;
+  }
+  return (scs_int)len;
+}
+
 // test hook (host only, no HIP call): the decision of reorder.h on a caller's matrix.  col_new2old (n) / row_new2old (m) receive the
 // numbering (identity when none is kept); info as scs_amd_get_reorder_info.  Returns 1 if a renumbering was kept, 0 if not, <0 on error.
 scs_int scs_amd_plan_reorder(const ScsMatrix *A, const ScsCone *k, scs_int *col_new2old, scs_int *row_new2old, double *info) {

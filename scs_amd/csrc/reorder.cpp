@@ -1,6 +1,9 @@
 // reorder.cpp -- see reorder.h.  Host code, setup time only (scs_init).
 #include "reorder.h"
 #include <thread>
+#include <functional>
+#include <exception>
+#include <system_error>
 #include <atomic>
 #include <algorithm>
 #include <chrono>
@@ -71,6 +74,47 @@ double lines_per_entry(const eoff *ptr, const int *idx, int rows, int cols, size
 
 namespace {
 
+// A piece of work on a side thread that cannot take the process down: an exception inside the work (std::bad_alloc of a
+// measurement's scratch at n = 1e6) is caught there and rethrown by join() on the joining thread -- where scs_init's catch turns it
+// into a NULL workspace, as before the threads existed; a thread that cannot be created (pid / thread limits) runs the work inline;
+// the destructor joins without throwing, so unwinding past a task in flight never reaches std::terminate through ~thread.
+class SideTask {
+  std::thread th;
+  std::function<void()> fn;
+  std::exception_ptr err;
+  void run() noexcept {
+    try {
+      fn();
+    } catch (...) {
+      err = std::current_exception();
+    }
+  }
+
+public:
+  SideTask() = default;
+  SideTask(const SideTask &) = delete;
+  SideTask &operator=(const SideTask &) = delete;
+  void start(std::function<void()> f) {
+    fn = std::move(f);
+    try {
+      th = std::thread([this] { run(); });
+    } catch (const std::system_error &) {
+      run(); // serial fallback
+    }
+  }
+  void join() {
+    if (th.joinable()) th.join();
+    if (err) {
+      std::exception_ptr e = err;
+      err = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  ~SideTask() {
+    if (th.joinable()) th.join();
+  }
+};
+
 struct Candidate {
   std::vector<int> col_new2old, row_new2old;
   double after[2] = {1, 1};
@@ -107,7 +151,8 @@ void measure(const HostCsc &A, Candidate &c) {
   std::vector<eoff> tp;
   std::vector<int> ti;
   // (the two measurements are independent passes over read-only patterns: one of them on a second host thread)
-  std::thread side([&] { c.after[1] = lines_per_entry(np.data(), ni.data(), n, m, sizeof(real)); });
+  SideTask side; // (declared after everything its work reads: joined before those go away, also on unwinding)
+  side.start([&] { c.after[1] = lines_per_entry(np.data(), ni.data(), n, m, sizeof(real)); });
   transpose_pattern(np.data(), ni.data(), n, m, tp, ti);
   c.after[0] = lines_per_entry(tp.data(), ti.data(), m, n, sizeof(real));
   side.join();
@@ -180,14 +225,22 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   std::vector<eoff> rptr; // CSR pattern of A (rows -> columns)
   std::vector<int> rcol;
   std::atomic<int> verdict{0}; // 0: not known yet, 1: go on, 2: the given numbering is already local
-  std::thread tb0([&] { R.before[1] = lines_per_entry(cp, ci, n, m, sizeof(real)); }); // A' product: rows = columns of A, gathers y
+  SideTask tb0, tb, t1; // destroyed (joined) before everything above; what t1 writes (c1) is declared below but outlives the joins: see c1
+  tb0.start([&] { R.before[1] = lines_per_entry(cp, ci, n, m, sizeof(real)); }); // A' product: rows = columns of A, gathers y
   transpose_pattern(cp, ci, n, m, rptr, rcol);
   // The line sharing of the GIVEN numbering is measured on a side thread while this one already starts on the candidates; if it turns
   // out local enough (the common case for problems that come in a sensible order) the searches are told to stop and their work --
   // at most the ~0.15 s the measurement takes -- is dropped.
   // (0.25, not the 0.8 at which spmv_wave.h switches kernels: rows that keep their place re-use a few columns many times and
   // so share lines in ANY numbering of the variables -- a scrambled band measures 0.49 / 0.94 -- while the rest gains 10x)
-  std::thread tb([&] {
+  tb.start([&] {
+    struct Always { // whatever happens in here, the searches must not wait for a verdict that never comes
+      std::atomic<int> &v;
+      ~Always() {
+        int zero = 0;
+        v.compare_exchange_strong(zero, 1, std::memory_order_release);
+      }
+    } always{verdict};
     R.before[0] = lines_per_entry(rptr.data(), rcol.data(), m, n, sizeof(real)); // A product: rows of A, gathers x
     tb0.join();
     verdict.store(0.5 * (R.before[0] + R.before[1]) <= 0.25 && force != 1 ? 2 : 1, std::memory_order_release);
@@ -197,14 +250,22 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   const bool dbg_t = opt_get("debug") != nullptr;
   if (dbg_t) fprintf(stderr, "[scs_amd reorder] first pass + transpose: %.0f ms\n", 1e3 * (now_s() - t0));
   std::vector<Candidate> cands;
-  Candidate c1;
+  Candidate c1; // written by t1: every path below joins t1 before c1 is read or goes out of scope (JoinFirst for the unwinding path)
+  struct JoinFirst {
+    SideTask &t;
+    ~JoinFirst() {
+      try {
+        t.join();
+      } catch (...) {
+      }
+    }
+  } c1_guard{t1};
   bool have_c1 = false;
-  std::thread t1;
   // ---- candidate 1: anchors.  A column is keyed by the mean position of its entries in rows that cannot move (only when every
   // column has such entries: the rest would need the graph search anyway), a free row by the mean NEW position of its columns.
   if (many_anchors && unkeyed == 0) {
     have_c1 = true;
-    t1 = std::thread([&] {
+    t1.start([&] {
     Candidate &c = c1;
     c.method = "anchors (mean position of a column's entries in the rows that cannot move)";
     c.col_new2old = order_by_key(ckey);
@@ -234,6 +295,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     std::vector<int> mark(nv, -1), order, scratch;
     order.reserve(nv);
     scratch.reserve(nv);
+    const int *rcol_p = rcol.data();
     auto bfs = [&](int start, int tag, std::vector<int> &q) -> int { // appends the component of `start` to q; returns the last vertex reached
       size_t head = q.size();
       q.push_back(start);
@@ -245,7 +307,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
         // two places down the queue, and the adjacency of the one six places down, are asked for now
         if (head + 6 < q.size()) {
           const int w = q[head + 6];
-          __builtin_prefetch(w < n ? (const void *)&ci[cp[w]] : (const void *)&rcol[rptr[w - n]]);
+          __builtin_prefetch(w < n ? (const void *)(ci + cp[w]) : (const void *)(rcol_p + rptr[w - n])); // raw pointers: an empty row at the end points one past the array
         }
         if (head + 2 < q.size()) {
           const int w = q[head + 2];
@@ -372,10 +434,13 @@ void apply_reorder(HostCsc &A, const Reorder &R) {
     }
   };
   const int nthr = n >= 100000 ? 4 : 1;
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nthr; ++t) pool.emplace_back(do_range, (int)((long long)n * t / nthr), (int)((long long)n * (t + 1) / nthr));
+  SideTask pool[3];
+  for (int t = 1; t < nthr; ++t) {
+    const int j0 = (int)((long long)n * t / nthr), j1 = (int)((long long)n * (t + 1) / nthr);
+    pool[t - 1].start([&do_range, j0, j1] { do_range(j0, j1); });
+  }
   do_range(0, (int)((long long)n / nthr));
-  for (std::thread &th : pool) th.join();
+  for (SideTask &th : pool) th.join();
   A = std::move(B);
 }
 

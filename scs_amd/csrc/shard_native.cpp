@@ -24,9 +24,11 @@ extern "C" {
 typedef struct ncclComm *ncclComm_t;
 #define NCCL_UNIQUE_ID_BYTES 128
 typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclFloat = 7, ncclDouble = 8 } ncclDataType_t;
-typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
+// (fixed underlying type: RCCL returns result codes 1..7 through these function pointers, which an enum that lists only 0 could not
+// formally hold -- with -fstrict-enums `rc != ncclSuccess` could be folded away)
+typedef enum : int { ncclSuccess = 0 } ncclResult_t;
+typedef enum : int { ncclFloat = 7, ncclDouble = 8 } ncclDataType_t;
+typedef enum : int { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
 }
 
 namespace scsamd {

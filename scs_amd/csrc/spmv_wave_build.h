@@ -151,9 +151,22 @@ inline bool wave_fill_dev(WaveRowsDev &w, const eoff *d_ptr, const int *d_idx, c
   const int bm_words = (int)((lines + 31) / 32);
   const size_t lds = WB_LDS_KEYS + WB_LDS_ROWL + (size_t)bm_words * 4;
   if (w.max_unit_entries() > WR_DEV_UNIT_MAX || lds > WB_LDS_MAX || w.nunit < 1) return false;
+  // the limit that counts is the device's opt-in LDS per workgroup (queried, not assumed), and the kernel's static LDS
+  // (its reduction array) counts against it too; a refused opt-in sends the matrix to the host builder instead of failing scs_init
+  {
+    int dev = 0, optin = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
+    hipFuncAttributes fa;
+    const void *kp = w.sub_window_order ? reinterpret_cast<const void *>(k_wave_layout<true>) : reinterpret_cast<const void *>(k_wave_layout<false>);
+    if (hipFuncGetAttributes(&fa, kp) != hipSuccess) return false;
+    if (lds + fa.sharedSizeBytes > (size_t)optin) return false;
+    if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+  }
   DevBuf<unsigned long long> cnt(1);
   auto launch = [&](auto kern) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(w.nunit), dim3(WB_THREADS), lds, st, d_ptr, d_idx, d_val, (const int *)w.urow.p, (const eoff *)w.useg.p,
                        w.wrd.p, w.val.p, w.cbits, w.bshift, lshift, bm_words, cnt.p);
   };

@@ -180,6 +180,38 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert d["value"] > 0 and d["window_it_per_s"] > 0 and abs(d["ms_per_step"] - 2.0) < 2.0
 
 
+def test_bench_eight_rank_dry_run_over_gloo():
+    """the first 8-GPU driver run must not fail on plumbing.  `--gpus 8` over gloo with the stub solver: eight
+    ranks rendezvous, the census sees all of them, the configs[3] batch is 64 problems split 8 per rank and every record comes
+    back through the all-gather, `value` = sum of the ranks' iterations / the slowest rank's wall time, and ONLY rank 0 writes to
+    stdout -- exactly one line (include/scs.h:271-324: scs_init / scs_solve are re-entrant, which is what makes the split legal)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--stub-solver", "--backend", "gloo",
+                          "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # ranks 1..7 print nothing on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks_seen"] == list(range(8)) and d["collective_backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["config"]["problems_per_gpu"] == 1
+    assert len(d["results_per_rank"]) == 8 and len(d["per_rank_it_per_s"]) == 8
+    iters = [int(r[1]) for r in d["results_per_rank"]]
+    assert iters == [25 * (2 + r) for r in range(8)]  # the stub's rank r converges at iteration 25 (2 + r)
+    # value = all ranks' iterations / max-over-ranks wall: the slowest rank (225 iterations of 2 ms) bounds the wall from below
+    wall = sum(iters) / d["value"]
+    assert 0.002 * 225 <= wall <= 0.002 * 225 * 3 + 2.0, wall
+    assert d["ms_per_iter_whole_solve"] == pytest.approx(1000.0 / d["value"], rel=1e-3)
+    b = d["batch"]
+    assert b["problems"] == 64 and b["problems_per_gpu"] == 8 and b["ranks"] == 8 and b["all_solved"] is True
+    assert b["iters_sum"] == sum(25 * (1 + j % 3) for j in range(64))  # every problem's record reached rank 0 exactly once
+    assert b["admm_iters_per_s"] == pytest.approx(b["iters_sum"] / b["wall_s"], rel=1e-3)
+    assert len(lines[0]) < 4096
+
+
 def test_bench_line_is_compact_and_carries_the_contract_keys(tmp_path):
     """the driver could not parse a 21 KB line.  The LAST stdout line must be one compact JSON object
     (< 4096 bytes) with the contract's keys; the full record goes to `detail_file` and, prefixed, to stderr.  Checked twice:
@@ -201,6 +233,10 @@ def test_bench_line_is_compact_and_carries_the_contract_keys(tmp_path):
     need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data", "config", "roofline", "cpu_baseline", "detail_file"}
     assert need <= set(d), need - set(d)
+    # `value` (whole solve) and `ms_per_step` (the timed window) describe different regions -- the line says so itself
+    assert {"value_definition", "ms_per_iter_whole_solve", "ms_per_step_definition"} <= set(d)
+    assert len(d["value_definition"]) <= 120 and d["ms_per_iter_whole_solve"] == pytest.approx(1000.0 / d["value"], rel=1e-3)
+    assert d["roofline"]["kernel"].startswith("stub")  # the label comes from the solver (scs_amd_get_spmv_kernel_name), not from a constant
     assert {"workload", "n", "m", "nnz"} <= set(d["config"]) and {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"} <= set(d["roofline"])
     assert json.loads(json.dumps(d)) == d
     full = json.load(open(d["detail_file"]))
@@ -215,6 +251,16 @@ def test_bench_line_is_compact_and_carries_the_contract_keys(tmp_path):
     assert c["roofline"]["frac"] == pytest.approx(big["roofline"]["frac"], rel=1e-5)
     assert c["parity_window"]["max_rel_diff"] == pytest.approx(big["parity_window"]["max_rel_diff"], rel=1e-5)
     assert c["batch"]["parity"]["ok"] is True and c["secondary"]["configs2_sdp"]["ms_per_projection"] > 0
+    # round 6 keys travel through the compaction: the many-small-SOC variant, the spread of iters_to_eps
+    big["secondary"]["headline_many_small_soc"] = dict(status="solved", q=8, soc_cones=150000, iters_to_eps=500, time_to_eps_s=9.0, value_it_per_s=55.5,
+                                                      cone_us_per_projection=20.0, workload="x" * 300)
+    big["iters_to_eps_spread"] = dict(observed=[475, 525, 575], reference_cpu=575, this_run=525, step=25, source="s")
+    big["roofline"]["kernel_short"] = "csr_wave_lockstep_kernel<EPI,16,4> (CSR SpMV, A and A')"
+    c = bench.compact_line(big, "/x/detail.json")
+    assert c["secondary"]["headline_many_small_soc"] == dict(status="solved", q=8, soc_cones=150000, iters_to_eps=500, time_to_eps_s=9.0,
+                                                             value_it_per_s=55.5, cone_us_per_projection=20.0)
+    assert c["iters_to_eps_spread"]["observed"] == [475, 525, 575] and c["roofline"]["kernel"].startswith("csr_wave_lockstep_kernel<EPI,16,4>")
+    assert len(json.dumps(c, separators=(",", ":"))) < bench.LINE_MAX_BYTES
     # an absurdly inflated record still yields a parseable line: optional blocks are shed, the contract keys stay
     big["config"]["workload"] = "x" * 5000
     big["secondary"]["locality_variant"] = {"k%d" % i: dict(roofline=dict(frac=0.1)) for i in range(400)}
