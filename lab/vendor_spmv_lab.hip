@@ -12,7 +12,8 @@
 // over back-to-back launches.
 //
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-deprecated-declarations lab/vendor_spmv_lab.hip -o lab/vendor_spmv_lab -lrocsparse -ldl
-// run  : lab/vendor_spmv_lab [cases: n:f64|f32,...] [--only-vendor alg]   (from the repository root: it dlopens scs_amd/lib/*.so)
+// run  : lab/vendor_spmv_lab [cases: n:f64|f32,...] [--only-vendor <substring of an algorithm's name> | none]   (from the repository root: it
+//        dlopens scs_amd/lib/*.so; scripts/vendor_spmv.sh runs one algorithm per process so that a fault in one leaves the others' rows)
 #include <hip/hip_runtime.h>
 #include <rocsparse/rocsparse.h>
 #include <dlfcn.h>
@@ -176,9 +177,6 @@ static void run_case(int n, const char *libpath, const char *only_vendor) {
   RS(rocsparse_create_handle(&hd));
   RS(rocsparse_set_stream(hd, st));
   const rocsparse_datatype dt = f64 ? rocsparse_datatype_f64_r : rocsparse_datatype_f32_r;
-  rocsparse_spmat_descr mA, mAt;
-  RS(rocsparse_create_csr_descr(&mA, m, n, nnz, d_rp, d_rj, d_rx, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, dt));
-  RS(rocsparse_create_csr_descr(&mAt, n, m, nnz, d_cp, d_ci, d_cx, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, dt));
   rocsparse_dnvec_descr vxn, vym, vom, von;
   RS(rocsparse_create_dnvec_descr(&vxn, n, d_xn, dt));
   RS(rocsparse_create_dnvec_descr(&vym, m, d_ym, dt));
@@ -197,13 +195,18 @@ static void run_case(int n, const char *libpath, const char *only_vendor) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (const Alg &al : algs) {
+    if (only_vendor && !strcmp(only_vendor, "none")) break;
     if (only_vendor && !strstr(al.name, only_vendor)) continue;
     double us[2];
     bool ok = true;
     for (int o = 0; o < 2; ++o) {
-      rocsparse_spmat_descr M = o ? mAt : mA;
+      // a FRESH matrix descriptor per (algorithm, orientation): the preprocess stage parks its analysis in the descriptor, and a second
+      // algorithm on a descriptor analysed for another one faulted the GPU (first run of this lab)
+      rocsparse_spmat_descr M;
+      if (o) RS(rocsparse_create_csr_descr(&M, n, m, nnz, d_cp, d_ci, d_cx, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, dt));
+      else RS(rocsparse_create_csr_descr(&M, m, n, nnz, d_rp, d_rj, d_rx, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, dt));
       rocsparse_dnvec_descr X = o ? vym : vxn, Y = o ? von : vom;
-      // a fresh descriptor per algorithm would be cleaner; the analysis data of one algorithm is not reused by another
+      fprintf(stderr, "[vendor_spmv_lab] %s, %s ...\n", al.name, o ? "A'" : "A");
       size_t bs = 0;
       void *buf = nullptr;
       rocsparse_status s = rocsparse_spmv(hd, rocsparse_operation_none, &alpha, M, X, &beta, Y, dt, al.alg, rocsparse_spmv_stage_buffer_size, &bs, nullptr);
@@ -236,6 +239,7 @@ static void run_case(int n, const char *libpath, const char *only_vendor) {
       ok = ok && check(al.name, o ? d_outn : d_outm, o ? want_at : want_a);
       printf("   (%s, %s: analysis %.1f ms, buffer %zu B)\n", al.name, o ? "A'" : "A", 1e3 * t_pre, bs);
       CK(hipFree(buf));
+      RS(rocsparse_destroy_spmat_descr(M));
     }
     if (ok) rows.push_back({al.name, us[0], us[1]});
     else printf("   (%s: not available for this matrix / build)\n", al.name);
@@ -243,7 +247,8 @@ static void run_case(int n, const char *libpath, const char *only_vendor) {
   RS(rocsparse_destroy_handle(hd));
 
   // ---------------- this library, through its B1 ABI on device pointers ----------------
-  if (!only_vendor) {
+  if (!only_vendor || !strcmp(only_vendor, "none")) {
+    fprintf(stderr, "[vendor_spmv_lab] this library ...\n");
     Lib<F> L;
     if (!L.open(libpath)) exit(4);
     ScsMatrixT<F> A{cx.data(), ci.data(), cp.data(), m, n};
@@ -308,6 +313,7 @@ int main(int argc, char **argv) {
     if (!strcmp(argv[i], "--only-vendor") && i + 1 < argc) only_vendor = argv[++i];
     else cases = argv[i];
   }
+  setvbuf(stdout, nullptr, _IOLBF, 0);
   printf("# SpMV on BASELINE's random-SOCP matrix: rocSPARSE csrmv beside this library's kernels, one process, one MI355X\n");
   size_t pos = 0;
   while (pos < cases.size()) {

@@ -145,6 +145,30 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
         wr_consume(A, cur, x, acc, e0 + lane * 4, t, cmask);
         cur = nxt;
       }
+    } else if (PIPE == 2) {
+      // round 6, mid-size systems (the batch config's n = 2e5: units of ~4 chunks, the gathered vector fits an XCD's L2, the matrix the
+      // Infinity Cache): the product is a chain of dependent round trips per wave -- stream, gathers, adds, once per chunk -- not a
+      // bandwidth problem.  TWO chunks per trip: both chunks' stream loads are issued together, then all eight gather instructions, then
+      // the adds in the plain kernel's order (chunk c before chunk c + 1, entry i before i + 1: the same bits as PIPE = 0).
+      for (eoff e0 = s; e0 < t; e0 += 512) {
+        const eoff ea = e0 + lane * 4, eb = ea + 256;
+        const bool two = e0 + 256 < t; // uniform (the padding behind a unit covers ONE chunk of over-read, not two)
+        const WrChunk c0 = wr_load(A, ea);
+        WrChunk c1 = c0;
+        if (two) c1 = wr_load(A, eb);
+        const unsigned w0[4] = {c0.w.x, c0.w.y, c0.w.z, c0.w.w}, w1[4] = {c1.w.x, c1.w.y, c1.w.z, c1.w.w};
+        real x0[4], x1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x0[i] = ea + i < t ? x[w0[i] & cmask] : (real)0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x1[i] = (two && eb + i < t) ? x[w1[i] & cmask] : (real)0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ea + i < t) lds_add(acc + (w0[i] >> A.cbits), c0.v[i] * x0[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (two && eb + i < t) lds_add(acc + (w1[i] >> A.cbits), c1.v[i] * x1[i]);
+      }
     } else {
       for (eoff e0 = s; e0 < t; e0 += 256) {
         const eoff eb = e0 + lane * 4;
@@ -319,7 +343,7 @@ struct WaveRowsDev {
     if (const char *b = opt_get("wr_ls_barriers")) ls_bmode = atoi(b) == 1 ? 1 : 4;
     if (const char *o = opt_get("wr_ls_order")) sub_window_order = atoi(o) != 0; // measurements: lockstep without the quarter-window chunk order
     if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
-    if (const char *e = opt_get("wr_wpc")) wpc = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = opt_get("wr_wpc")) wpc = std::max(1, std::min(32, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
     if (const char *e = opt_get("wr_nnz")) budget = std::max(64, atoi(e));
     auto partition = [&](long long bud) {
@@ -372,7 +396,7 @@ struct WaveRowsDev {
   void finish(long long distinct) {
     lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
     pipelined = lines_per_entry < 0.8 ? 1 : 0;
-    if (const char *e = opt_get("wr_pipe")) pipelined = atoi(e) != 0 ? 1 : 0; // tests / measurements force either
+    if (const char *e = opt_get("wr_pipe")) pipelined = std::max(0, std::min(2, atoi(e))); // tests / measurements force 0 | 1 | 2 (two chunks per trip)
     // lockstep: a barrier in front of every gather instruction when every gather is its own line, one per chunk when a unit's
     // gathers share lines anyway (band of 1024 rows at the headline sizes: 34.0 vs 35.3 us per product; uniformly random: 65.1 vs 62.2)
     if (ls_bmode < 0) ls_bmode = lines_per_entry < 0.3 ? 1 : 4;

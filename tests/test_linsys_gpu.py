@@ -191,7 +191,7 @@ def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(mon
     monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")
     monkeypatch.setenv("SCS_AMD_DEBUG", "1")
     outs = []
-    for pipe in (None, "0", "1"):
+    for pipe in (None, "0", "1", "2"):   # 2 (round 6): two chunks per round trip, the mid-size instantiation
         if pipe is None:
             monkeypatch.delenv("SCS_AMD_WR_PIPE", raising=False)
         else:
@@ -208,6 +208,16 @@ def test_banded_matrix_takes_the_pipelined_wave_kernel_and_matches_reference(mon
         wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
         ref.scs_free_lin_sys_work(wr)
         assert np.abs(outs[0] - xr).max() <= 1e-8 * np.abs(xr).max()
+    # units of ODD chunk counts (a last trip with one chunk) and of a single short chunk: two-chunk trips against the plain kernel
+    for unit_nnz in ("700", "130"):
+        monkeypatch.setenv("SCS_AMD_WR_NNZ", unit_nnz)
+        pair = []
+        for pipe in ("0", "2"):
+            monkeypatch.setenv("SCS_AMD_WR_PIPE", pipe)
+            w, out = _solve_with(amd, prob.matA, None, dr, b, s, 1e-12)
+            amd.scs_free_lin_sys_work(w)
+            pair.append(out)
+        assert np.array_equal(pair[0], pair[1]), unit_nnz
 
 
 @pytest.mark.parametrize("wpb,bars,unit_nnz,wpc", [("16", "4", "600", None), ("16", "1", "1500", "1"), ("8", "4", "300", "2")])

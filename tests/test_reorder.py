@@ -2,7 +2,8 @@
 
 A banded SOCP handed over in an arbitrary numbering of its variables and of the rows of its zero / nonnegative cones must be
 recognised and renumbered so that the gathers of the two CSR products (linsys/scs_matrix.c:161-186) share cache lines again;
-a uniformly random pattern (the headline benchmark family) must be left alone after one cheap pass; rows of every other cone never move
+a uniformly random pattern (the headline benchmark family) has nothing to recover and gets the chain + home numbering instead
+(round 6); the first row of a second-order cone and the rows of box / PSD / exponential / power cones never move
 (include/scs.h:121-172: their order is part of the cone)."""
 import ctypes as C
 
@@ -55,14 +56,38 @@ def test_scrambled_band_is_recovered_and_anchored_rows_do_not_move(band, monkeyp
     assert got_a < 0.5 * scr_a and got_at < 0.5 * scr_at
 
 
-def test_uniformly_random_pattern_is_left_alone(monkeypatch):
+def test_uniformly_random_pattern_gets_the_chain_and_home_numbering(monkeypatch):
+    """Round 6.  A uniformly random pattern (the headline benchmark family) has no hidden locality -- rounds 4-5 left it alone after
+    one pass -- but a fixed share of its gathers can be MADE local: columns numbered along walks in which neighbours share a row, and
+    every movable row (zero cone, nonnegative cone, the tail of a second-order cone: the norm does not depend on the order of its
+    arguments, src/cones.c:1247-1279) at the position of its first column.  ~3 of 10 entries per column: 0.96 -> ~0.73 distinct
+    lines per entry.  Checked: permutations, every row inside its cone's range with the cone's FIRST row in place, the improvement
+    re-measured here on the renumbered matrix, and the same numbering on a second call (the walks run on a fixed number of ranges)."""
     monkeypatch.delenv("SCS_AMD_REORDER", raising=False)
     lib = capi.load("libscsamd.so")
-    pr = problems.random_socp(120000, 240000, 10, seed=5)   # 1.2e6 nonzeros: the library does look at it
+    n, m = 120000, 240000
+    pr = problems.random_socp(n, m, 10, seed=5)                  # 1.2e6 nonzeros: the library does look at it
     rc, info, cp, rp = _plan(pr, lib)
-    assert rc == 0 and info[0] == 0.0
-    assert np.array_equal(cp, np.arange(120000)) and np.array_equal(rp, np.arange(240000))
-    assert info[5] < 0.5                                        # recognised in one pass over the pattern (seconds)
+    assert rc == 1 and info[0] == 1.0
+    assert sorted(cp) == list(range(n)) and sorted(rp) == list(range(m))
+    cone = pr["cone"]
+    z, l = cone["z"], cone["l"]
+    assert set(rp[:z]) == set(range(z)) and set(rp[z:z + l]) == set(range(z, z + l))
+    o, moved_tail = z + l, 0
+    for q in cone["q"]:
+        assert rp[o] == o                                        # t of [t; x] stays the cone's first row
+        assert set(rp[o:o + q]) == set(range(o, o + q))          # x is permuted inside its own cone only
+        moved_tail += int(np.count_nonzero(rp[o:o + q] != np.arange(o, o + q)))
+        o += q
+    assert o == m and moved_tail > 0.5 * (m - z - l)
+    assert 0.5 * (info[3] + info[4]) <= 0.8 * 0.5 * (info[1] + info[2]), info
+    A2 = pr["A"][rp][:, cp]
+    got_a, got_at = _lines_per_entry(A2.tocsr(), 128), _lines_per_entry(A2.T.tocsr(), 64)
+    was_a, was_at = _lines_per_entry(pr["A"].tocsr(), 128), _lines_per_entry(pr["A"].T.tocsr(), 64)
+    assert got_a <= 0.85 * was_a and got_at <= 0.85 * was_at, (got_a, was_a, got_at, was_at)
+    rc2, info2, cp2, rp2 = _plan(pr, lib)
+    assert rc2 == 1 and np.array_equal(cp, cp2) and np.array_equal(rp, rp2)
+    assert info[5] < 2.0                                         # seconds (0.1 s here at this size)
 
 
 def test_pure_lp_without_anchors_uses_the_graph_search(monkeypatch):
