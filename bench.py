@@ -985,7 +985,7 @@ def main():
     it = S.steps(W)
     stats0 = S.stats()
     if not args.no_kernel_timing:
-        S.profiling(True)  # samples 1 in 8 SpMV launches with HIP events on OUR stream
+        S.profiling(True)  # samples 1 in 7 SpMV launches (an odd period: alternates A and A') with HIP events on OUR stream
     barrier()
     t0 = time.perf_counter()
     it2 = S.steps(K)

@@ -293,8 +293,8 @@ scs_int scs_amd_solve_end(ScsWork *w, ScsSolution *sol, ScsInfo *info);
 /* test hook: every per-iteration linear solve uses this tolerance instead of the
  * schedule of src/scs.c:745-762 (0 restores the schedule) */
 void scs_amd_set_cg_tol_override(ScsWork *w, double tol);
-/* What scs_init decided about its internal numbering (scs_amd/csrc/reorder.h: variables and the rows of the zero / nonnegative
- * cones may be renumbered so that the gathers of the CSR products of linsys/scs_matrix.c:161-186 share cache lines; callers never see
+/* What scs_init decided about its internal numbering (scs_amd/csrc/reorder.h: variables, the rows of the zero / nonnegative
+ * cones and -- round 6 -- the rows behind the first one of a second-order cone may be renumbered so that the gathers of the CSR products of linsys/scs_matrix.c:161-186 share cache lines; callers never see
  * it -- b, c, warm starts and the returned (x, y, s) are mapped at this boundary).  out[0] = 1 if renumbered, out[1], out[2] =
  * distinct 128-byte lines per gathered entry of the A / A' product as given, out[3], out[4] = after, out[5] = seconds spent. */
 void scs_amd_get_reorder_info(const ScsWork *w, double *out);

@@ -279,9 +279,9 @@ static void run_case(int n, const char *libpath, const char *only_vendor) {
         Stats s0, s1;
         L.stats(w, &s0);
         const double t0 = now_s();
-        for (int r = 0; r < 8 * reps; ++r) go(); // every 8th launch is event-timed
+        for (int r = 0; r < 7 * reps; ++r) go(); // every 7th launch is event-timed
         L.sync(w);
-        wall[o] = 1e6 * (now_s() - t0) / (8 * reps);
+        wall[o] = 1e6 * (now_s() - t0) / (7 * reps);
         L.stats(w, &s1);
         L.prof(w, 0);
         us[o] = 1e3 * (s1.spmv_ms - s0.spmv_ms) / std::max<long long>(1, s1.spmv_launches - s0.spmv_launches);

@@ -9,24 +9,21 @@ OUT=$R/gpurun_out/${1:-psdclk}
 mkdir -p $OUT
 cd $R
 cp scs_amd/lib/libscsamd.so /tmp/lib_shipped.so
-cp scs_amd/lib_var/psdclk/libscsamd.so scs_amd/lib/libscsamd.so
+cp scs_amd/lib_var/${3:-psdclk}/libscsamd.so scs_amd/lib/libscsamd.so
 : > $OUT/psd_clocks.md
 for pipe in 1 0; do
   SCS_AMD_PSD_PIPE=$pipe timeout 300 python scripts/bench_sdp.py ${2:-} > $OUT/psdclk_pipe$pipe.log 2>&1
   python - $OUT/psdclk_pipe$pipe.log $pipe >> $OUT/psd_clocks.md <<'PY'
 import sys, re
 rows = []
-for l in open(sys.argv[1]):
-    if l.startswith("PSDCLK"):
-        f = l.split()
-        rows.append({f[i]: float(f[i + 1]) for i in range(1, len(f) - 1, 2)})
-cone = [l.strip() for l in open(sys.argv[1]) if l.startswith("cone:")]
+txt = open(sys.argv[1]).read()  # (device printf and the host's prints share the pipe: lines can run into each other -> patterns, not line splits)
+for m in re.finditer(r"PSDCLK pipe (\d+) k (\d+) unpack_warm (\d+) fro (\d+) sweeps (\d+) tail (\d+) nsweep (\d+) steps (\d+) rot_steps (\d+)", txt):
+    rows.append(dict(zip(("pipe", "k", "unpack_warm", "fro", "sweeps", "tail", "nsweep", "steps", "rot_steps"), map(float, m.groups()))))
+cone = [l.strip() for l in txt.splitlines() if l.startswith("cone:")]
 wv = {}
-for l in open(sys.argv[1]):
-    if l.startswith("PSDWAVE"):
-        f = l.split()
-        d = wv.setdefault(f[1], [0.0, 0.0, 0])
-        d[0] += float(f[3]); d[1] += float(f[5]); d[2] += 1
+for m in re.finditer(r"PSDWAVE (\w+) work (\d+) wait (\d+)", txt):
+    d = wv.setdefault(m.group(1), [0.0, 0.0, 0])
+    d[0] += float(m.group(2)); d[1] += float(m.group(3)); d[2] += 1
 if not rows:
     print("pipe", sys.argv[2], ": no PSDCLK lines"); sys.exit(0)
 n = len(rows)

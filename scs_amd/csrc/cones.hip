@@ -51,7 +51,15 @@ constexpr int PSD_MAX_PAIRS = 512;    // supports k <= 1024
 #define PSD_COUNT(x)
 #endif
 constexpr int PSD_TBL = 256;          // second rotation-table buffer of the pipelined step (LDS path: <= 46 pairs)
+#ifdef SCSAMD_PSD_LA_ALONE
+// measurement variant (round 6): the look-ahead wave (wave 7) ALONE on its SIMD -- wave 3, which shares SIMD 3 with it (waves go to the
+// SIMDs round robin), only keeps the barriers company; six update waves, four rows of V per lane
+constexpr int PSD_PIPE_THREADS = PSD_THREADS - 128;
+constexpr int PSD_PIPE_VR = 4;
+#else
 constexpr int PSD_PIPE_THREADS = PSD_THREADS - 64; // update lanes of the pipelined step (the last wave looks ahead)
+constexpr int PSD_PIPE_VR = 3;
+#endif
 constexpr int PSD_K_LIMIT = 2 * PSD_MAX_PAIRS;
 constexpr size_t PSD_LDS_HEADER = PSD_MAX_PAIRS * (2 * sizeof(real) + 2 * sizeof(int)) + 10 * sizeof(real);
 
@@ -573,8 +581,13 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     // of two, and the rotation chain (two rsqrt sequences on <= 36 lanes) off the critical path.  NB = 2x2 blocks per update lane.
     auto sweeps_pipelined = [&](auto nbc) {
       constexpr int NB = decltype(nbc)::value;
-      PsdItems<NB> items;
-      psd_items_init<NB>(items, tid, PSD_PIPE_THREADS, npairs, K2); // the lane's blocks and row pairs: once, not per step
+      PsdItems<NB, PSD_PIPE_VR> items;
+#ifdef SCSAMD_PSD_LA_ALONE
+      const int utid = wave < 3 ? tid : (wave == 3 ? PSD_PIPE_THREADS : tid - 64); // wave 3 idle: an index no item belongs to
+#else
+      const int utid = tid;
+#endif
+      psd_items_init<NB, PSD_PIPE_VR>(items, utid, PSD_PIPE_THREADS, npairs, K2); // the lane's blocks and row pairs: once, not per step
       if (la) __builtin_amdgcn_s_setprio(3); // the look-ahead wave's chain is the longer one: it issues first on its SIMD
       for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
         if (nothing_to_rotate()) break;
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
               if (step + 2 < K2 - 1) la_prepare(); // for the phase after the barrier
             }
           } else {
-            rotates = psd_update_pass<NB>(Acur, Anext, V, tq, tc, items, ld, rot_any + par) != 0; // the flag is read with the tables (uniform)
+            rotates = psd_update_pass<NB, PSD_PIPE_VR>(Acur, Anext, V, tq, tc, items, ld, rot_any + par) != 0; // the flag is read with the tables (uniform)
           }
 #ifdef SCSAMD_PSD_CLOCKS
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -660,8 +673,8 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     // 1 + (K2 - 2 - i + s) mod (K2 - 1)); the two positions advance by one per step (no run-time modulus on the step's critical path)
     auto sweeps_two_phase = [&](auto nbc) {
       constexpr int NB = decltype(nbc)::value;
-      PsdItems<NB> items;
-      psd_items_init<NB>(items, tid, PSD_THREADS, npairs, K2);
+      PsdItems<NB, 3> items;
+      psd_items_init<NB, 3>(items, tid, PSD_THREADS, npairs, K2);
       for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
         if (nothing_to_rotate()) break;
         real offmax = 0;
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
           if (!rot_any[par]) continue; // uniform: every pair of this step is already converged
           PSD_COUNT(n_rot_steps);
           // A <- J' A J in ONE pass over 2x2 blocks (rows of pair P, columns of pair Q); V <- V J over (row, pair) items
-          psd_update_pass<NB>(A, A, V, rot_pq, rot_cs, items, ld);
+          psd_update_pass<NB, 3>(A, A, V, rot_pq, rot_cs, items, ld);
           __syncthreads();
         }
         offmax = block_max(offmax, red);
@@ -691,7 +704,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     };
     using std::integral_constant;
     if (pipelined) {
-      switch (psd_blocks_per_lane(npairs, PSD_PIPE_THREADS)) { // blocks of the upper triangle per update lane (K2 <= 72: at most 2)
+      switch (psd_blocks_per_lane(npairs, PSD_PIPE_THREADS, PSD_PIPE_VR)) { // blocks of the upper triangle per update lane (K2 <= 72: at most 2)
       case 1: sweeps_pipelined(integral_constant<int, 1>()); break;
       default: sweeps_pipelined(integral_constant<int, 2>()); break;
       }

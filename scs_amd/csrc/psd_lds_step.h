@@ -74,22 +74,22 @@ PSD_HD void jacobi_cs(real d, real b, real &c, real &s) {
 // max(r, c) -- so a step updates npairs (npairs + 1) / 2 blocks instead of npairs^2, with half the LDS traffic and half the
 // arithmetic on A, and A stays symmetric by construction (rounds 2-4 computed both triangles, equal only to rounding, and read one).
 // The lower triangle is never read after the warm start.
-template <int NB>
+template <int NB, int VR = 3> // VR: rows of V per lane and block (3 ships; 4 with six update waves, the look-ahead wave alone on its SIMD)
 struct PsdItems {
-  int bP[NB], bQ[NB], vQ, vI[3 * NB];
-  bool okb[NB], okv[3 * NB];
+  int bP[NB], bQ[NB], vQ, vI[VR * NB];
+  bool okb[NB], okv[VR * NB];
 };
 // blocks per lane for `nthreads` update lanes: the upper triangle of the npairs x npairs block grid, NB blocks per lane; the (row,
 // pair) items of V: a lane takes up to 3 NB consecutive rows of ONE pair Q (one table read serves them all), so npairs *
 // ceil(K2 / (3 NB)) lanes must exist
-PSD_HD int psd_v_groups(int K2, int nb) { return (K2 + 3 * nb - 1) / (3 * nb); }
-PSD_HD int psd_blocks_per_lane(int npairs, int nthreads) {
+PSD_HD int psd_v_groups(int K2, int nb, int vr = 3) { return (K2 + vr * nb - 1) / (vr * nb); }
+PSD_HD int psd_blocks_per_lane(int npairs, int nthreads, int vr = 3) {
   int nb = (npairs * (npairs + 1) / 2 + nthreads - 1) / nthreads;
-  while (npairs * psd_v_groups(2 * npairs, nb) > nthreads) ++nb;
+  while (npairs * psd_v_groups(2 * npairs, nb, vr) > nthreads) ++nb;
   return nb;
 }
-template <int NB>
-PSD_HD void psd_items_init(PsdItems<NB> &it, int tid, int nthreads, int npairs, int K2) {
+template <int NB, int VR>
+PSD_HD void psd_items_init(PsdItems<NB, VR> &it, int tid, int nthreads, int npairs, int K2) {
   const int ntri = npairs * (npairs + 1) / 2;
   PSD_UNROLL
   for (int u = 0; u < NB; ++u) {
@@ -104,20 +104,30 @@ PSD_HD void psd_items_init(PsdItems<NB> &it, int tid, int nthreads, int npairs, 
     it.bQ[u] = Q;
     it.bP[u] = it.okb[u] ? e - Q * (Q + 1) / 2 : 0;
   }
-  const int G = psd_v_groups(K2, NB); // lanes per pair Q
+  const int G = psd_v_groups(K2, NB, VR); // lanes per pair Q
   const bool lane_ok = tid < nthreads && tid < npairs * G;
   const int tq = lane_ok ? tid : 0;
   it.vQ = tq / G;
-  const int i0 = (tq % G) * 3 * NB;
+  const int i0 = (tq % G) * VR * NB;
   PSD_UNROLL
-  for (int j = 0; j < 3 * NB; ++j) {
+  for (int j = 0; j < VR * NB; ++j) {
     it.okv[j] = lane_ok && i0 + j < K2;
     it.vI[j] = it.okv[j] ? i0 + j : 0; // consecutive lanes: rows 3 NB apart, stride 3 NB ld
   }
 }
 
-// where entry (r, c) of the symmetric matrix is stored
-PSD_HD int psd_sym_index(int r, int c, int ld) { return r < c ? r * ld + c : c * ld + r; }
+// where entry (r, c) of the symmetric matrix is stored.  (Device: the 24-bit multiply-add -- orders and leading dimensions are < 100 --
+// is a full-rate instruction; the 32-bit r * ld + c compiles to v_mad_u64_u32, a quarter-rate one, four times per block of the update
+// pass and six times on the look-ahead wave's chain in every step.)
+#ifdef PSD_STEP_HOST_CHECK
+PSD_HD int psd_mad24(int a, int b, int c) { return a * b + c; }
+#else
+PSD_HD int psd_mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+#endif
+PSD_HD int psd_sym_index(int r, int c, int ld) {
+  const int lo = r < c ? r : c, hi = r < c ? c : r;
+  return psd_mad24(lo, ld, hi);
+}
 
 // One update pass, A_dst <- J' A_src J over the 2x2 blocks (rows of pair P, columns of pair Q, P <= Q) and V <- V J over (row, pair)
 // items: every lane owns up to NB blocks and 3 NB row pairs and asks for all its tables, then all its operands, before it computes
@@ -125,14 +135,14 @@ PSD_HD int psd_sym_index(int r, int c, int ld) { return r < c ? r * ld + c : c *
 // 0 for the loads and skipped by the stores (no per-item branches in the load phase).  A_dst == A_src is the in-place form (every
 // entry is read and written by the same lane); the pipelined step passes the other copy.
 // Returns the flag (1 without one).
-template <int NB>
-PSD_HD int psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB> &it,
+template <int NB, int VR>
+PSD_HD int psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB, VR> &it,
                            int ld, const int *rotates_flag = nullptr) {
   // pipelined step: "does this step rotate at all" is a word in LDS; it is asked for together with the tables (ONE round trip for the
   // flag, the block's two pairs and the row pairs' pair -- left alone the compiler reads the flag, waits, branches, reads the block's
   // tables, waits, reads the rows' table, waits: four dependent round trips per step where two are needed)
   int flag = rotates_flag ? *rotates_flag : 1;
-  constexpr int NV = 3 * NB;
+  constexpr int NV = VR * NB;
   int i11[NB], i12[NB], i21[NB], i22[NB];
   RotCS r1[NB], r2[NB];
   PsdPair q1[NB], q2[NB];
@@ -164,8 +174,8 @@ PSD_HD int psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair 
   int ip[NV], iq[NV];
   PSD_UNROLL
   for (int j = 0; j < NV; ++j) {
-    ip[j] = it.vI[j] * ld + pqv.x;
-    iq[j] = it.vI[j] * ld + pqv.y;
+    ip[j] = psd_mad24(it.vI[j], ld, pqv.x);
+    iq[j] = psd_mad24(it.vI[j], ld, pqv.y);
   }
   real a11[NB], a12[NB], a21[NB], a22[NB], vp[NV], vq[NV];
   PSD_UNROLL
@@ -267,8 +277,8 @@ PSD_HD void psd_la_prepare(PsdLaPlan &pl, const PsdRot &P, const PsdRot &Q, int 
   pl.a[1] = psd_sym_index(P.x, Q.y, ld);
   pl.a[2] = psd_sym_index(P.y, Q.x, ld);
   pl.a[3] = psd_sym_index(P.y, Q.y, ld);
-  pl.a[4] = p * ld + p;
-  pl.a[5] = q * ld + q;
+  pl.a[4] = psd_mad24(p, ld, p);
+  pl.a[5] = psd_mad24(q, ld, q);
   pl.a[6] = psd_sym_index(P.x, P.y, ld);
   pl.a[7] = psd_sym_index(Q.x, Q.y, ld);
   // row-rotation coefficients of the update: first player (c, -s), second player (s, c)
@@ -310,8 +320,8 @@ PSD_HD bool psd_first_rotation(const real *A, int p, int q, int ld, int k, real 
   const real apq = A[psd_sym_index(p, q, ld)];
   real app = 0, aqq = 0;
   if ((p > q ? p : q) < k && psd_abs(apq) > thr) {
-    app = A[p * ld + p];
-    aqq = A[q * ld + q];
+    app = A[psd_mad24(p, ld, p)];
+    aqq = A[psd_mad24(q, ld, q)];
   }
   return psd_make_rotation(apq, app, aqq, p, q, k, thr, offmax, out);
 }

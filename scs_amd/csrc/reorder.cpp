@@ -17,10 +17,96 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// A piece of work on a side thread that cannot take the process down (ADVICE r5): an exception inside the work (std::bad_alloc of a
+// measurement's scratch at n = 1e6) is caught there and rethrown by join() on the joining thread -- where scs_init's catch turns it
+// into a NULL workspace, as before the threads existed; a thread that cannot be created (pid / thread limits) runs the work inline;
+// the destructor joins without throwing, so unwinding past a task in flight never reaches std::terminate through ~thread.
+class SideTask {
+  std::thread th;
+  std::function<void()> fn;
+  std::exception_ptr err;
+  void run() noexcept {
+    try {
+      fn();
+    } catch (...) {
+      err = std::current_exception();
+    }
+  }
+
+public:
+  SideTask() = default;
+  SideTask(const SideTask &) = delete;
+  SideTask &operator=(const SideTask &) = delete;
+  void start(std::function<void()> f) {
+    fn = std::move(f);
+    try {
+      th = std::thread([this] { run(); });
+    } catch (const std::system_error &) {
+      run(); // serial fallback
+    }
+  }
+  void join() {
+    if (th.joinable()) th.join();
+    if (err) {
+      std::exception_ptr e = err;
+      err = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  ~SideTask() {
+    if (th.joinable()) th.join();
+  }
+};
+
+constexpr int TR_THREADS = 4; // fixed (results do not depend on it, only the time does)
+
 // transpose of a pattern: (ptr, idx) with `rows` rows over `cols` columns -> (tptr, tidx) with `cols` rows (counting sort,
-// like linsys/cpu/indirect/private.c:7-46 without the values)
+// like linsys/cpu/indirect/private.c:7-46 without the values).  From a million entries on the two passes over the entries run on
+// TR_THREADS ranges of source rows with per-range counts; an entry's place is its row's start + the entries of the same output row in
+// EARLIER source rows, so the result is the serial counting sort's, byte for byte.
 void transpose_pattern(const eoff *ptr, const int *idx, int rows, int cols, std::vector<eoff> &tptr, std::vector<int> &tidx) {
   const size_t nnz = (size_t)ptr[rows];
+  if (nnz >= 1000000 && rows >= 4 * TR_THREADS) {
+    int r0[TR_THREADS + 1];
+    for (int t = 0; t <= TR_THREADS; ++t) { // ranges of source rows with about equal numbers of entries
+      const eoff want = (eoff)((double)nnz * t / TR_THREADS);
+      r0[t] = t == TR_THREADS ? rows : (int)(std::lower_bound(ptr, ptr + rows, want) - ptr);
+    }
+    std::vector<std::vector<unsigned>> cnt(TR_THREADS);
+    {
+      SideTask th[TR_THREADS - 1];
+      auto count = [&](int t) {
+        cnt[t].assign((size_t)cols, 0u);
+        for (eoff k = ptr[r0[t]]; k < ptr[r0[t + 1]]; ++k) cnt[t][(size_t)idx[k]]++;
+      };
+      for (int t = 1; t < TR_THREADS; ++t) th[t - 1].start([&count, t] { count(t); });
+      count(0);
+      for (SideTask &x : th) x.join();
+    }
+    tptr.assign((size_t)cols + 1, 0);
+    for (int c = 0; c < cols; ++c) { // per-range counts -> per-range first positions (in place), row starts
+      eoff run = tptr[c];
+      for (int t = 0; t < TR_THREADS; ++t) {
+        const unsigned k = cnt[t][(size_t)c];
+        cnt[t][(size_t)c] = (unsigned)(run - tptr[c]); // offset inside the output row: < 2^32 (a row of A or A' is far shorter)
+        run += k;
+      }
+      tptr[(size_t)c + 1] = run;
+    }
+    tidx.resize(nnz);
+    {
+      SideTask th[TR_THREADS - 1];
+      auto fill = [&](int t) {
+        std::vector<unsigned> &off = cnt[t];
+        for (int r = r0[t]; r < r0[t + 1]; ++r)
+          for (eoff k = ptr[r]; k < ptr[r + 1]; ++k) tidx[(size_t)(tptr[idx[k]] + off[(size_t)idx[k]]++)] = r;
+      };
+      for (int t = 1; t < TR_THREADS; ++t) th[t - 1].start([&fill, t] { fill(t); });
+      fill(0);
+      for (SideTask &x : th) x.join();
+    }
+    return;
+  }
   tptr.assign((size_t)cols + 1, 0);
   for (size_t k = 0; k < nnz; ++k) tptr[(size_t)idx[k] + 1]++;
   for (int c = 0; c < cols; ++c) tptr[c + 1] += tptr[c];
@@ -74,47 +160,6 @@ double lines_per_entry(const eoff *ptr, const int *idx, int rows, int cols, size
 
 namespace {
 
-// A piece of work on a side thread that cannot take the process down (ADVICE r5): an exception inside the work (std::bad_alloc of a
-// measurement's scratch at n = 1e6) is caught there and rethrown by join() on the joining thread -- where scs_init's catch turns it
-// into a NULL workspace, as before the threads existed; a thread that cannot be created (pid / thread limits) runs the work inline;
-// the destructor joins without throwing, so unwinding past a task in flight never reaches std::terminate through ~thread.
-class SideTask {
-  std::thread th;
-  std::function<void()> fn;
-  std::exception_ptr err;
-  void run() noexcept {
-    try {
-      fn();
-    } catch (...) {
-      err = std::current_exception();
-    }
-  }
-
-public:
-  SideTask() = default;
-  SideTask(const SideTask &) = delete;
-  SideTask &operator=(const SideTask &) = delete;
-  void start(std::function<void()> f) {
-    fn = std::move(f);
-    try {
-      th = std::thread([this] { run(); });
-    } catch (const std::system_error &) {
-      run(); // serial fallback
-    }
-  }
-  void join() {
-    if (th.joinable()) th.join();
-    if (err) {
-      std::exception_ptr e = err;
-      err = nullptr;
-      std::rethrow_exception(e);
-    }
-  }
-  ~SideTask() {
-    if (th.joinable()) th.join();
-  }
-};
-
 struct Candidate {
   std::vector<int> col_new2old, row_new2old;
   double after[2] = {1, 1};
@@ -143,10 +188,21 @@ void measure(const HostCsc &A, Candidate &c) {
   std::vector<eoff> np((size_t)n + 1, 0);
   std::vector<int> ni((size_t)cp[n]);
   for (int j = 0; j < n; ++j) np[j + 1] = np[j] + (cp[c.col_new2old[j] + 1] - cp[c.col_new2old[j]]);
-  for (int j = 0; j < n; ++j) {
-    eoff o = np[j];
-    const int jo = c.col_new2old[j];
-    for (eoff q = cp[jo]; q < cp[jo + 1]; ++q) ni[(size_t)o++] = row_old2new[ci[q]];
+  auto fill = [&](int j0, int j1) {
+    for (int j = j0; j < j1; ++j) {
+      eoff o = np[j];
+      const int jo = c.col_new2old[j];
+      for (eoff q = cp[jo]; q < cp[jo + 1]; ++q) ni[(size_t)o++] = row_old2new[ci[q]];
+    }
+  };
+  {
+    SideTask th[TR_THREADS - 1];
+    for (int t = 1; t < TR_THREADS; ++t) {
+      const int j0 = (int)((long long)n * t / TR_THREADS), j1 = (int)((long long)n * (t + 1) / TR_THREADS);
+      th[t - 1].start([&fill, j0, j1] { fill(j0, j1); });
+    }
+    fill(0, (int)((long long)n / TR_THREADS));
+    for (SideTask &x : th) x.join();
   }
   std::vector<eoff> tp;
   std::vector<int> ti;
@@ -243,11 +299,24 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
   std::vector<int> colpos((size_t)n);
   for (int j = 0; j < n; ++j) colpos[c.col_new2old[j]] = j;
   // ---- home: first column (in the new order) of every row
+  // Which of its columns a row calls home: ONE PICKED BY A HASH OF THE ROW, not the first in the new order.  With the first column
+  // (measured, profiles/r6_chain_home.md) a row's other entries all lie to the right of its home, so a unit of rows late in the
+  // order gathers from a compressed range of x and falls out of step with the window of x the rest of the chip is gathering from
+  // (spmv_wave.h keeps that window L2-resident): the A product went from 64.8 to 72.1 us although its L1 -> L2 requests fell by
+  // 19 %.  A hashed choice keeps a unit's entries uniform over the columns and the homes uniform over the rows.
+  int home_mode = 1;
+  if (const char *e = opt_get("reorder_home")) home_mode = atoi(e);
   std::vector<int> home((size_t)m, n); // n = a row without entries: behind the others
   auto homes = [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r) {
+      const eoff a = rptr[r], b = rptr[r + 1];
       int h = n;
-      for (eoff e = rptr[r]; e < rptr[r + 1]; ++e) h = std::min(h, colpos[rcol[e]]);
+      if (home_mode == 0) {
+        for (eoff e = a; e < b; ++e) h = std::min(h, colpos[rcol[e]]);
+      } else if (b > a) {
+        const unsigned hsh = ((unsigned)r * 2654435761u) >> 8;
+        h = colpos[rcol[a + (eoff)(hsh % (unsigned)(b - a))]];
+      }
       home[r] = h;
     }
   };

@@ -14,7 +14,14 @@
 // (b) without enough anchors (pure LPs) a breadth-first Cuthill-McKee numbering of the bipartite row / column graph from
 // a pseudo-peripheral start.  The candidate is kept only if the MEASURED line sharing (distinct 128-byte lines of the
 // gathered vector per entry, per unit of rows as spmv_wave.h cuts them) improves by 20 % or more; a uniformly random
-// matrix (the headline benchmark) is recognised from the spread of its anchors in one pass over the pattern and skipped.
+// matrix (the headline benchmark) is recognised from the spread of its anchors in one pass over the pattern and goes to (c).
+// (c) round 6 -- "chain + home" for patterns WITHOUT hidden locality (what rounds 4-5 skipped): nothing can make most gathers of a
+// uniformly random matrix share lines, but a fixed share can be made local by construction -- columns numbered along greedy walks in
+// which neighbours share a row (one line of x serves both entries of that row; the neighbouring columns ask for the same y entry),
+// and every movable row placed, inside its cone's range, at the position of its first column.  Movable here also means the TAIL of a
+// second-order cone: |x|_2 does not depend on the order of x (src/cones.c:1247-1279), D is constant inside a cone
+// (linsys/scs_matrix.c:257,329) and R_y too (src/cones.c:349-363); the cone's first row t stays.  ~3 of 10 entries per column turn
+// local on the headline family: 0.96 / 0.98 -> 0.75 / 0.71 distinct lines per gathered entry (kept from 15 % on).
 // The solve then runs entirely in the new numbering; scs_update / warm starts / the returned (x, y, s) are mapped at the
 // API boundary (admm.hip), so callers never see it.  P != NULL disables it (a symmetric permutation of the upper triangle
 // is not implemented).  SCS_AMD_REORDER=0 switches it off, =1 forces the attempt on small problems too (tests).

@@ -21,9 +21,9 @@ constexpr int NT_PIPE = 448;  // PSD_THREADS - the look-ahead wave
 template <int NB>
 void update_all(const real *As, real *Ad, real *V, const PsdPair *pq, const RotCS *cs, int npairs, int K2, int ld, int nt) {
   for (int tid = 0; tid < nt; ++tid) {
-    PsdItems<NB> it;
-    psd_items_init<NB>(it, tid, nt, npairs, K2);
-    psd_update_pass<NB>(As, Ad, V, pq, cs, it, ld);
+    PsdItems<NB, 3> it;
+    psd_items_init<NB, 3>(it, tid, nt, npairs, K2);
+    psd_update_pass<NB, 3>(As, Ad, V, pq, cs, it, ld);
   }
 }
 void update_dispatch(const real *As, real *Ad, real *V, const PsdPair *pq, const RotCS *cs, int npairs, int K2, int ld, int nt) {
