@@ -407,7 +407,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
   }
   const bool dbg_early = opt_get("debug") != nullptr;
   const bool many_anchors = anchored * 5 >= nnz; // a fifth of the entries sit in rows that cannot move
-  if (many_anchors && force != 1) {
+  if (many_anchors) { // (also when the attempt is forced: a pattern without hidden locality goes to candidate 3 either way)
     // k anchors drawn uniformly from the fixed rows span (k - 1) / (k + 1) of them on average (0.6 - 0.7 on the benchmark family);
     // a hidden band spans a sliver.  Nothing to recover from a uniformly random pattern: say so after this one pass.
     const double mean_spread = spread_cols ? spread_sum / (double)spread_cols : 1.0;

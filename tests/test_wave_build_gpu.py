@@ -50,6 +50,26 @@ def test_device_layout_equals_host_layout(monkeypatch, libname, n, m, col_nnz, b
     assert 0 < info[2] <= 1.0 + 1e-9 and 0 < info[5] <= 1.0 + 1e-9
 
 
+@pytest.mark.parametrize("lockstep", ["0", "1"])
+@pytest.mark.parametrize("libname", ["libscsamd.so", "libscsamd_f32.so"])
+def test_heavy_buckets_first_device_layout_equals_host_layout(monkeypatch, libname, lockstep):
+    """Round 6: under the chain + home numbering (forced on at this size) a fifth of a unit's entries sit in the few column buckets
+    around the unit's home; both builders move such heavy buckets to the front of the unit (wr_bucket_heavy, spmv_wave.h).  verify mode
+    compares every byte; the numbering must really have produced heavy buckets (lines per entry well below 1)."""
+    lib = capi.load(libname)
+    T = lib._scs_types
+    pr = problems.random_socp(30000, 60000, 10, seed=77)
+    prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=T)
+    monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")
+    monkeypatch.setenv("SCS_AMD_REORDER", "1")
+    monkeypatch.setenv("SCS_AMD_WR_LOCKSTEP", lockstep)
+    monkeypatch.setenv("SCS_AMD_WR_BUILD", "verify")
+    monkeypatch.setenv("SCS_AMD_TRANSPOSE", "verify")
+    info = _layout_info(lib, prob)
+    assert info[0] == 1 and info[3] == 1 and info[1] == 1 and info[4] == 1, info
+    assert info[2] < 0.9 and info[5] < 0.9, info
+
+
 def test_rows_of_a_few_thousand_entries_stay_on_the_device(monkeypatch):
     """a row of 3000 entries: the device transpose sorts it with one workgroup (bitonic in LDS), and its unit still fits the device
     layout builder"""
