@@ -16,6 +16,10 @@
 // one control block per batch; kernels issued past convergence return at once,
 // so the iterate returned is exactly the first one meeting the tolerance.
 #include "linsys.h"
+#include <thread>
+#include <exception>
+#include <system_error>
+#include <algorithm>
 #include "spmv_wave_build.h"
 #include <algorithm>
 #include <atomic>
@@ -922,6 +926,59 @@ static void host_transpose(int rows_out, int cols_out, const eoff *Ap, const int
   Cp.assign((size_t)rows_out + 1, 0);
   Ci.resize((size_t)nnz);
   Cx.resize((size_t)nnz);
+  // From a few million entries on (the B1 boundary hands over host arrays; round 6's nnz = 2.2e9 run spent most of its 132 s of
+  // scs_init_lin_sys_work in this loop): four ranges of columns with their own counts -- an entry's place is its row's start plus the
+  // entries of that row in EARLIER columns, so the result is the serial loop's, byte for byte.
+  constexpr int TT = 4;
+  if (nnz >= 4000000 && cols_out >= 4 * TT) {
+    int c0[TT + 1];
+    for (int t = 0; t <= TT; ++t) c0[t] = t == TT ? cols_out : (int)(std::lower_bound(Ap, Ap + cols_out, (eoff)((double)nnz * t / TT)) - Ap);
+    std::vector<std::vector<unsigned>> cnt(TT);
+    std::exception_ptr err[TT];
+    auto run = [&](auto fn) { // a std::bad_alloc inside a worker must reach the caller's catch, not std::terminate
+      std::vector<std::thread> th;
+      for (int t = 0; t < TT; ++t) err[t] = nullptr;
+      auto body = [&](int t) {
+        try {
+          fn(t);
+        } catch (...) {
+          err[t] = std::current_exception();
+        }
+      };
+      try {
+        for (int t = 1; t < TT; ++t) th.emplace_back(body, t);
+      } catch (const std::system_error &) {
+        for (int t = (int)th.size() + 1; t < TT; ++t) body(t); // serial fallback for the ranges without a thread
+      }
+      body(0);
+      for (std::thread &x : th) x.join();
+      for (int t = 0; t < TT; ++t)
+        if (err[t]) std::rethrow_exception(err[t]);
+    };
+    run([&](int t) {
+      cnt[t].assign((size_t)rows_out, 0u);
+      for (eoff k = Ap[c0[t]]; k < Ap[c0[t + 1]]; ++k) cnt[t][(size_t)Ai[k]]++;
+    });
+    for (int i = 0; i < rows_out; ++i) {
+      eoff run_ = Cp[i];
+      for (int t = 0; t < TT; ++t) {
+        const unsigned c = cnt[t][(size_t)i];
+        cnt[t][(size_t)i] = (unsigned)(run_ - Cp[i]);
+        run_ += c;
+      }
+      Cp[(size_t)i + 1] = run_;
+    }
+    run([&](int t) {
+      std::vector<unsigned> &off = cnt[t];
+      for (int j = c0[t]; j < c0[t + 1]; ++j)
+        for (eoff k = Ap[j]; k < Ap[j + 1]; ++k) {
+          const eoff q = Cp[Ai[k]] + off[(size_t)Ai[k]]++;
+          Ci[(size_t)q] = j;
+          Cx[(size_t)q] = Ax[k];
+        }
+    });
+    return;
+  }
   for (long long k = 0; k < nnz; ++k) Cp[(size_t)Ai[k] + 1]++;
   for (int i = 0; i < rows_out; ++i) Cp[i + 1] += Cp[i];
   std::vector<eoff> nxt(Cp.begin(), Cp.end() - 1);

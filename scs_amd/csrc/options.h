@@ -58,7 +58,7 @@ struct OptRow {
   X("wr_wpc",           OPT_AB,        1, "1..16",            "resident waves per CU the wave layout is cut for") \
   X("wr_nnz",           OPT_AB,        1, "n",                "nonzero budget per unit of the wave layout") \
   X("wr_pipe",          OPT_AB,        0, "0|1|2",            "instantiation of the plain wave SpMV: 1 = next chunk's stream in flight ahead of the gathers, 2 = two chunks per round trip (default: from the size and the measured line sharing)") \
-  X("reorder_home",     OPT_AB,        1, "0|1",              "chain + home numbering: a row's home is its first column in the new order (0) or one picked by a hash of the row (1, default)") \
+  X("reorder_home",     OPT_AB,        1, "0|1|2",            "chain + home numbering: a row's home is its first column in the new order (0), one picked by a hash of the row (1, default), or rows are left where they are (2)") \
   X("vec_nt",           OPT_AB,        0, "0|1|3",            "non-temporal policy of the CG vector kernels") \
   X("dir_mode",         OPT_AB,        0, "n",                "variant of k_cg_direction") \
   X("cg3",              OPT_AB,        1, "0|1",              "three launches per CG iteration (k_cg3_update; default off)") \

@@ -304,7 +304,7 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
   // order gathers from a compressed range of x and falls out of step with the window of x the rest of the chip is gathering from
   // (spmv_wave.h keeps that window L2-resident): the A product went from 64.8 to 72.1 us although its L1 -> L2 requests fell by
   // 19 %.  A hashed choice keeps a unit's entries uniform over the columns and the homes uniform over the rows.
-  int home_mode = 1;
+  int home_mode = 1; // 0: first column, 1: hashed column (default), 2: rows stay where they are (chain only; measurements)
   if (const char *e = opt_get("reorder_home")) home_mode = atoi(e);
   std::vector<int> home((size_t)m, n); // n = a row without entries: behind the others
   auto homes = [&](int r0, int r1) {
@@ -348,7 +348,8 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
   std::iota(c.row_new2old.begin(), c.row_new2old.end(), 0);
   std::vector<int> cursor(rg.size());
   for (size_t g = 0; g < rg.size(); ++g) cursor[g] = rg[g].first;
-  for (int r : sorted) c.row_new2old[(size_t)cursor[range_of[r]]++] = r;
+  if (home_mode != 2)
+    for (int r : sorted) c.row_new2old[(size_t)cursor[range_of[r]]++] = r;
   if (dbg) fprintf(stderr, "[scs_amd reorder] chain + home: walks done at +0, homes %.0f ms, row placement %.0f ms\n", 1e3 * (th_ - tw), 1e3 * (now_s() - th_));
 }
 
@@ -374,6 +375,12 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     return;
   }
   if (m < 2 || n < 2) return;
+  // beyond 2^26 rows or columns the packed word of the wave-owned-rows layout has no room for the column (spmv_wave.h, col_bits): the
+  // products run through the CSR-stream kernel, and a decision that costs a minute of host time at nnz = 2e9 would buy nothing
+  if ((m > (1 << 26) || n > (1 << 26)) && force != 1) {
+    R.why = "more than 2^26 rows or columns (no wave-owned-rows layout to help)";
+    return;
+  }
   const int z = (int)k->z, lp = (int)k->l, fixed0 = z + lp; // rows [0, z) and [z, z + l) may move inside their range; the rest are anchors
   const eoff *cp = A.p.data();
   const int *ci = A.i.data();
@@ -411,6 +418,13 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     // k anchors drawn uniformly from the fixed rows span (k - 1) / (k + 1) of them on average (0.6 - 0.7 on the benchmark family);
     // a hidden band spans a sliver.  Nothing to recover from a uniformly random pattern: say so after this one pass.
     const double mean_spread = spread_cols ? spread_sum / (double)spread_cols : 1.0;
+    if (mean_spread > 0.25 && sizeof(real) == 4 && force != 1) {
+      // fp32 (configs[4], n = 4e6): measured a LOSS -- 273 -> 279 us per product with the numbering, and 2.3 s more scs_init
+      // (profiles/r6_chain_home.md): the plain wave kernel of the fp32 build gains nothing from the shared lines.  Left alone.
+      R.why = "no hidden locality (fp32 build: the chain + home numbering measured slower, not attempted)";
+      R.seconds = now_s() - t0;
+      return;
+    }
     if (mean_spread > 0.25) {
       // no hidden locality to recover (rounds 4-5 stopped here): what CAN be had by construction is candidate 3 (round 6)
       std::vector<eoff> rptr0;

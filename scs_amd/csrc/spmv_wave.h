@@ -35,15 +35,6 @@ constexpr int WR_ROWS_MAX = 1024;   // rows per unit (8 KB of fp64 accumulators 
 constexpr int WR_MAX_GRID = 4096;   // partial-array bound for the fused dot product
 constexpr int WR_BUCKETS = 1024;    // column buckets per unit (ordering heuristic only)
 
-// heavy buckets of a unit (both layout builders, host and device, use exactly these two)
-#ifdef __HIPCC__
-#define WR_HD __host__ __device__ __forceinline__
-#else
-#define WR_HD inline
-#endif
-WR_HD int wr_buckets_used(int cols, int bshift) { return ((cols > 0 ? cols - 1 : 0) >> bshift) + 1; }
-WR_HD bool wr_bucket_heavy(int count, int nbuckets, long long unit_entries) { return count >= 32 && (long long)count * nbuckets > 8 * unit_entries; }
-
 struct WaveView {
   int rows, nunit, cbits, cols;
   const int *urow;     // nunit + 1 : first row of each unit
@@ -416,26 +407,16 @@ struct WaveRowsDev {
     hv.assign(cap, (real)0);
     // stable counting sort of every unit by column bucket (ordering is a locality heuristic: any
     // order gives the same sums up to rounding)
-    // round 6: HEAVY buckets first.  A bucket that holds far more of the unit's entries than its share (>= 32 entries and > 8x the
-    // average: the unit's "home" window under the chain + home numbering of reorder.cpp, 20 % of its entries in one bucket) goes to
-    // the front of the unit, in bucket order; the other buckets follow as before.  Left in place, those entries shift every later
-    // chunk of the unit by their count, and units with different homes fall out of step with the window of x the chip is gathering
-    // from.  A uniformly random unit has no heavy bucket (order unchanged); a banded one has only heavy buckets (order unchanged).
-    std::vector<int> hist(WR_BUCKETS), cnt(2 * WR_BUCKETS + 1);
-    const int nbk = wr_buckets_used(cols, bshift);
+    std::vector<int> cnt(WR_BUCKETS + 1);
     for (int u = 0; u < nunit; ++u) {
       const eoff k0 = hptr[ur[u]], k1 = hptr[ur[u + 1]];
-      std::fill(hist.begin(), hist.end(), 0);
-      for (eoff k = k0; k < k1; ++k) hist[hidx[k] >> bshift]++;
-      const long long len = (long long)(k1 - k0);
-      auto slot = [&](int b) { return wr_bucket_heavy(hist[b], nbk, len) ? b : WR_BUCKETS + b; };
       std::fill(cnt.begin(), cnt.end(), 0);
-      for (eoff k = k0; k < k1; ++k) cnt[slot(hidx[k] >> bshift) + 1]++;
-      for (int b = 0; b < 2 * WR_BUCKETS; ++b) cnt[b + 1] += cnt[b];
+      for (eoff k = k0; k < k1; ++k) cnt[(hidx[k] >> bshift) + 1]++;
+      for (int b = 0; b < WR_BUCKETS; ++b) cnt[b + 1] += cnt[b];
       const size_t base = (size_t)us[2 * u];
       for (int rr = ur[u]; rr < ur[u + 1]; ++rr)
         for (eoff k = hptr[rr]; k < hptr[rr + 1]; ++k) {
-          const size_t qq = base + cnt[slot(hidx[k] >> bshift)]++;
+          const size_t qq = base + cnt[hidx[k] >> bshift]++;
           hw[qq] = (unsigned)hidx[k] | ((unsigned)(rr - ur[u]) << cbits);
           hv[qq] = hval[k];
         }

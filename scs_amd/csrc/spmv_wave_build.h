@@ -7,9 +7,8 @@
 // linsys/gpu/indirect/private.c:328-344 with device work, as the reference's own GPU backend does.
 //
 // One workgroup per unit (a unit = the <= 1024 consecutive rows one wave owns; its entries fit LDS):
-//   1. key = (slot << 13) | t, t = the entry's position in the unit's CSR order, slot = the entry's column bucket, heavy buckets (round 6,
-//      wr_bucket_heavy: a histogram of the unit's buckets in LDS) ahead of the others; an in-LDS bitonic sort of these unique keys IS
-//      the host's stable counting sort by slot (ties in row-major order);
+//   1. key = (column bucket << 13) | t, t = the entry's position in the unit's CSR order; an in-LDS bitonic sort of these unique
+//      keys IS the host's stable counting sort by bucket (ties in row-major order);
 //   2. lockstep layout only: inside every 256-entry chunk of that order, key = (column << 21) | (position in chunk << 13) | t,
 //      chunk-local bitonic sort = the host's stable sort by column; rank r of a chunk then goes to position 4 (r % 64) + r / 64
 //      (short last chunk: ranks dealt to the valid positions in the same i-major order as the host);
@@ -65,13 +64,12 @@ template <bool SUBWIN>
 __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const eoff *__restrict__ ptr, const int *__restrict__ idx,
                                                             const real *__restrict__ val, const int *__restrict__ urow,
                                                             const eoff *__restrict__ useg, unsigned *wrd, real *vout, int cbits,
-                                                            int bshift, int lshift, int bm_words, unsigned long long *distinct, int nbk) {
+                                                            int bshift, int lshift, int bm_words, unsigned long long *distinct) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wb_smem[];
   unsigned long long *key64 = reinterpret_cast<unsigned long long *>(wb_smem);
   unsigned *key32 = reinterpret_cast<unsigned *>(wb_smem);
   unsigned short *rowl = reinterpret_cast<unsigned short *>(wb_smem + WB_LDS_KEYS);
-  unsigned *hist = reinterpret_cast<unsigned *>(wb_smem + WB_LDS_KEYS + WB_LDS_ROWL); // entries per column bucket (heavy buckets first)
-  unsigned *bm = hist + WR_BUCKETS;
+  unsigned *bm = reinterpret_cast<unsigned *>(wb_smem + WB_LDS_KEYS + WB_LDS_ROWL);
   __shared__ unsigned red[WB_THREADS / 64];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int r0 = urow[u], r1 = urow[u + 1];
@@ -81,18 +79,13 @@ __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const eoff *__restri
   int P2 = 256;
   while (P2 < len) P2 <<= 1;
   for (int w = tid; w < bm_words; w += WB_THREADS) bm[w] = 0;
-  for (int w = tid; w < WR_BUCKETS; w += WB_THREADS) hist[w] = 0;
   for (int rr = r0 + tid; rr < r1; rr += WB_THREADS)
     for (eoff k = ptr[rr]; k < ptr[rr + 1]; ++k) rowl[k - k0] = (unsigned short)(rr - r0);
-  __syncthreads();
-  for (int t = tid; t < len; t += WB_THREADS) atomicAdd(&hist[(unsigned)idx[k0 + t] >> bshift], 1u); // integer counts: order independent
   __syncthreads();
   for (int t = tid; t < P2; t += WB_THREADS) {
     if (t < len) {
       const unsigned col = (unsigned)idx[k0 + t];
-      const unsigned b = col >> bshift;
-      const unsigned slot = wr_bucket_heavy((int)hist[b], nbk, (long long)len) ? b : (unsigned)WR_BUCKETS + b; // 11 bits + 13 bits of t
-      key32[t] = (slot << 13) | (unsigned)t;
+      key32[t] = ((col >> bshift) << 13) | (unsigned)t;
       const unsigned line = col >> lshift;
       atomicOr(&bm[line >> 5], 1u << (line & 31));
     } else {
@@ -156,7 +149,7 @@ inline bool wave_fill_dev(WaveRowsDev &w, const eoff *d_ptr, const int *d_idx, c
   const int lshift = sizeof(real) == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
   const long long lines = ((long long)w.cols >> lshift) + 1;
   const int bm_words = (int)((lines + 31) / 32);
-  const size_t lds = WB_LDS_KEYS + WB_LDS_ROWL + (size_t)WR_BUCKETS * 4 + (size_t)bm_words * 4;
+  const size_t lds = WB_LDS_KEYS + WB_LDS_ROWL + (size_t)bm_words * 4;
   if (w.max_unit_entries() > WR_DEV_UNIT_MAX || lds > WB_LDS_MAX || w.nunit < 1) return false;
   // the limit that counts is the device's opt-in LDS per workgroup (queried, not assumed), and the kernel's static LDS
   // (its reduction array) counts against it too; a refused opt-in sends the matrix to the host builder instead of failing scs_init
@@ -175,7 +168,7 @@ inline bool wave_fill_dev(WaveRowsDev &w, const eoff *d_ptr, const int *d_idx, c
   DevBuf<unsigned long long> cnt(1);
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(w.nunit), dim3(WB_THREADS), lds, st, d_ptr, d_idx, d_val, (const int *)w.urow.p, (const eoff *)w.useg.p,
-                       w.wrd.p, w.val.p, w.cbits, w.bshift, lshift, bm_words, cnt.p, wr_buckets_used(w.cols, w.bshift));
+                       w.wrd.p, w.val.p, w.cbits, w.bshift, lshift, bm_words, cnt.p);
   };
   if (w.sub_window_order) launch(k_wave_layout<true>);
   else launch(k_wave_layout<false>);
