@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet (fp64 matrix = fp64 vector); the guide lists no fp64 figure
 # committed PMC passes the static roofline.traffic field is read from: the newest round's that exists
-PMC_TRAFFIC_JSON = next((f for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
+PMC_TRAFFIC_JSON = next((f for f in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
                         "r2_pmc_traffic.json")
 
 
