@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 # (DESIGN.md section 4).  Measured on the GPU box at this test's size (n = 1.2e5, gpurun_out/r5a): 9.0e-13, 9.0e-4, 0.146, 0.146
 # (the last row repeats the returned state) -- the bounds are those figures x 2 (row 0: the 1e-10 asked for).  At the headline size
 # the same rows measure 3.6e-14, 6.7e-5, 6.8e-3, 0.215 (bench line, parity_window.max_rel_diff_by_iter).
-PARITY_WINDOW_BOUNDS = [1e-10, 1.8e-3, 0.3, 0.3]
+# Round 6: at this size scs_init now renumbers the problem (chain + home, reorder.cpp) -- another summation order in every product, so
+# row 1 (O(CG tolerance)) moved to 2.2e-3 (gpurun_out/r6tests); its bound is that x 2.
+PARITY_WINDOW_BOUNDS = [1e-10, 4.4e-3, 0.3, 0.3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -74,7 +76,9 @@ def test_one_rank_under_torchrun_runs_its_collectives_over_rccl():
     assert rccl["status"] == plain["status"] == "solved"
     assert rccl["iters_to_eps"] == plain["iters_to_eps"]            # bit-reproducible solve, same seed
     assert rccl["final"]["pobj"] == plain["final"]["pobj"]
-    assert abs(rccl["value"] - plain["value"]) <= 0.03 * plain["value"], (rccl["value"], plain["value"])
+    # (same work, two processes: the rates agree to the run-to-run spread of a 1.5 s solve sharing the box's host with the other test
+    # processes -- measured up to 5 %; the point of this test is the collectives, the iterations and the objective above)
+    assert abs(rccl["value"] - plain["value"]) <= 0.10 * plain["value"], (rccl["value"], plain["value"])
     assert len(rccl["per_rank_it_per_s"]) == 1 and rccl["per_rank_it_per_s"][0] > 0
     assert rccl["batch"]["problems"] == 2 and rccl["batch"]["all_solved"]
 
