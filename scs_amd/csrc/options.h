@@ -58,7 +58,9 @@ struct OptRow {
   X("wr_wpc",           OPT_AB,        1, "1..16",            "resident waves per CU the wave layout is cut for") \
   X("wr_nnz",           OPT_AB,        1, "n",                "nonzero budget per unit of the wave layout") \
   X("wr_pipe",          OPT_AB,        0, "0|1|2",            "instantiation of the plain wave SpMV: 1 = next chunk's stream in flight ahead of the gathers, 2 = two chunks per round trip (default: from the size and the measured line sharing)") \
-  X("reorder_home",     OPT_AB,        1, "0|1|2",            "chain + home numbering: a row's home is its first column in the new order (0), one picked by a hash of the row (1, default), or rows are left where they are (2)") \
+  X("reorder_home",     OPT_AB,        1, "0|1|2|3|4",        "chain + home numbering, how the movable rows are placed: 4 (default) = grouped by a hashed home column, line-sized groups dealt wide (blocked stride); 1 = plain home order; 0 = home is the first column; 2 = rows stay (chain only); 3 = homes only, columns as given") \
+  X("reorder_block",    OPT_AB,        1, "rows",             "chain + home numbering, blocked stride: rows per block (default: one 128-byte line of the gathered vector)") \
+  X("reorder_stride",   OPT_AB,        1, "blocks",           "chain + home numbering, blocked stride: blocks per stream (default 32; 0 = sqrt(blocks) streams)") \
   X("vec_nt",           OPT_AB,        0, "0|1|3",            "non-temporal policy of the CG vector kernels") \
   X("dir_mode",         OPT_AB,        0, "n",                "variant of k_cg_direction") \
   X("cg3",              OPT_AB,        1, "0|1",              "three launches per CG iteration (k_cg3_update; default off)") \

@@ -250,7 +250,7 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
   const int m = A.m, n = A.n;
   const eoff *cp = A.p.data();
   const int *ci = A.i.data();
-  c.method = "chain + home (columns along walks that share a row, movable rows at their first column)";
+  c.method = "chain + home (columns along walks that share a row; movable rows grouped by a home column, line-sized groups dealt wide)";
   // ---- chain: greedy walks, one set per fixed column range
   std::vector<unsigned char> visited((size_t)n, 0);
   std::vector<std::vector<int>> part(HOME_THREADS);
@@ -296,6 +296,8 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
   c.col_new2old.clear();
   c.col_new2old.reserve((size_t)n);
   for (int t = 0; t < HOME_THREADS; ++t) c.col_new2old.insert(c.col_new2old.end(), part[t].begin(), part[t].end());
+  if (const char *e = opt_get("reorder_home"))
+    if (atoi(e) == 3) std::iota(c.col_new2old.begin(), c.col_new2old.end(), 0); // measurements: homes only, columns as given
   std::vector<int> colpos((size_t)n);
   for (int j = 0; j < n; ++j) colpos[c.col_new2old[j]] = j;
   // ---- home: first column (in the new order) of every row
@@ -304,7 +306,7 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
   // order gathers from a compressed range of x and falls out of step with the window of x the rest of the chip is gathering from
   // (spmv_wave.h keeps that window L2-resident): the A product went from 64.8 to 72.1 us although its L1 -> L2 requests fell by
   // 19 %.  A hashed choice keeps a unit's entries uniform over the columns and the homes uniform over the rows.
-  int home_mode = 1; // 0: first column, 1: hashed column (default), 2: rows stay where they are (chain only; measurements)
+  int home_mode = 4; // 4 (default): hashed homes in blocked stride; measurements: 0 first column, 1 hashed column in plain home order, 2 rows stay (chain only), 3 hashed homes with the columns as given
   if (const char *e = opt_get("reorder_home")) home_mode = atoi(e);
   std::vector<int> home((size_t)m, n); // n = a row without entries: behind the others
   auto homes = [&](int r0, int r1) {
@@ -350,6 +352,32 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
   for (size_t g = 0; g < rg.size(); ++g) cursor[g] = rg[g].first;
   if (home_mode != 2)
     for (int r : sorted) c.row_new2old[(size_t)cursor[range_of[r]]++] = r;
+  if (home_mode == 4) {
+    // Blocked stride (round 6, measured; profiles/r6_chain_home.md): rows in plain home order make a unit of ~500 consecutive rows put
+    // a fifth of its entries on ONE spot of x -- the A product then pays more L2 misses than the shared lines save (65.5 -> 67.5 us
+    // while the A' product gains 12; homes alone, without the chain: 69.7).  What both products need is only that rows with
+    // neighbouring homes share a LINE: blocks of one line's worth of rows stay together, and the blocks of a range are dealt to
+    // streams of `per_stream` blocks, so that consecutive blocks are far apart in home order and a unit's homes spread over all of
+    // x.  A product 67.5 -> 57.1 us, A' 55.5 -> 56.1 us, same request counts.
+    int B = (int)(128 / sizeof(real)), per_stream = 32; // (measured: 8 ... 64 blocks per stream within 1 %, sqrt(blocks) streams 1.5 % behind)
+    if (const char *e = opt_get("reorder_block")) B = std::max(1, atoi(e));
+    if (const char *e = opt_get("reorder_stride")) per_stream = std::max(0, atoi(e)); // blocks per stream (0: sqrt(blocks) streams)
+    std::vector<int> tmp;
+    for (size_t g = 0; g < rg.size(); ++g) {
+      const int a = rg[g].first, len = rg[g].second - a;
+      const int nb = (len + B - 1) / B;
+      if (nb < 4) continue;
+      int S = 1;
+      if (per_stream > 0) S = std::max(1, nb / per_stream);
+      else
+        while ((long long)S * S < nb) ++S;
+      tmp.assign(c.row_new2old.begin() + a, c.row_new2old.begin() + a + len);
+      int o = a;
+      for (int st = 0; st < S; ++st)
+        for (int b = st; b < nb; b += S)
+          for (int t = b * B; t < std::min(len, (b + 1) * B); ++t) c.row_new2old[(size_t)o++] = tmp[(size_t)t];
+    }
+  }
   if (dbg) fprintf(stderr, "[scs_amd reorder] chain + home: walks done at +0, homes %.0f ms, row placement %.0f ms\n", 1e3 * (th_ - tw), 1e3 * (now_s() - th_));
 }
 
@@ -418,15 +446,10 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     // k anchors drawn uniformly from the fixed rows span (k - 1) / (k + 1) of them on average (0.6 - 0.7 on the benchmark family);
     // a hidden band spans a sliver.  Nothing to recover from a uniformly random pattern: say so after this one pass.
     const double mean_spread = spread_cols ? spread_sum / (double)spread_cols : 1.0;
-    if (mean_spread > 0.25 && sizeof(real) == 4 && force != 1) {
-      // fp32 (configs[4], n = 4e6): measured a LOSS -- 273 -> 279 us per product with the numbering, and 2.3 s more scs_init
-      // (profiles/r6_chain_home.md): the plain wave kernel of the fp32 build gains nothing from the shared lines.  Left alone.
-      R.why = "no hidden locality (fp32 build: the chain + home numbering measured slower, not attempted)";
-      R.seconds = now_s() - t0;
-      return;
-    }
     if (mean_spread > 0.25) {
-      // no hidden locality to recover (rounds 4-5 stopped here): what CAN be had by construction is candidate 3 (round 6)
+      // no hidden locality to recover (rounds 4-5 stopped here): what CAN be had by construction is candidate 3 (round 6).
+      // (fp32 too: with the rows in plain home order it had measured a loss there, 273 -> 279 us per product at n = 4e6; in blocked
+      // stride it gains, 275 -> 256 us, for 2.7 s more scs_init on a 20 s solve)
       std::vector<eoff> rptr0;
       std::vector<int> rcol0;
       SideTask tb1;
@@ -445,7 +468,7 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
       R.after[1] = c3.after[1];
       R.method = c3.method;
       const double before = 0.5 * (R.before[0] + R.before[1]), after = 0.5 * (c3.after[0] + c3.after[1]);
-      if (after <= 0.85 * before) {
+      if (after <= 0.85 * before || force == 1) { // (forced attempts keep the candidate whatever it measures: A/B runs of its parts)
         R.active = true;
         R.col_new2old = std::move(c3.col_new2old);
         R.row_new2old = std::move(c3.row_new2old);
