@@ -446,10 +446,16 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     // k anchors drawn uniformly from the fixed rows span (k - 1) / (k + 1) of them on average (0.6 - 0.7 on the benchmark family);
     // a hidden band spans a sliver.  Nothing to recover from a uniformly random pattern: say so after this one pass.
     const double mean_spread = spread_cols ? spread_sum / (double)spread_cols : 1.0;
+    if (mean_spread > 0.25 && sizeof(real) == 4 && force != 1) {
+      // fp32 (configs[4], n = 4e6), measured: in blocked stride the product gains (275 -> 256 us) but scs_init grows by 2.7 s and the
+      // one to-eps run under the numbering needed 525 iterations instead of 350 (fp32 sits close to its rounding floor at eps = 1e-3 and
+      // the other summation order moved it): 22.4 + 3.1 s against 20.7 + 0.4 s.  Not attempted in the fp32 build.
+      R.why = "no hidden locality (fp32 build: the chain + home numbering is not attempted, see reorder.cpp)";
+      R.seconds = now_s() - t0;
+      return;
+    }
     if (mean_spread > 0.25) {
-      // no hidden locality to recover (rounds 4-5 stopped here): what CAN be had by construction is candidate 3 (round 6).
-      // (fp32 too: with the rows in plain home order it had measured a loss there, 273 -> 279 us per product at n = 4e6; in blocked
-      // stride it gains, 275 -> 256 us, for 2.7 s more scs_init on a 20 s solve)
+      // no hidden locality to recover (rounds 4-5 stopped here): what CAN be had by construction is candidate 3 (round 6)
       std::vector<eoff> rptr0;
       std::vector<int> rcol0;
       SideTask tb1;

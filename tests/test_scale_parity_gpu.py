@@ -122,7 +122,12 @@ def test_fp32_at_1e5_against_fp32_reference_and_known_optimum(monkeypatch):
     pr = problems.random_socp(n, m, 10, seed=4, dtype=np.float32)
     prob = capi.Problem(pr["A"], pr["b"], pr["c"], pr["cone"], T=capi.T32)
     kw = dict(verbose=0, acceleration_lookback=0, eps_abs=1e-3, eps_rel=1e-3)
+    # leg (i) in the CALLER's numbering (option reorder = 0): two fp32 trajectories are compared after a fixed number of inexact
+    # iterations, and round 6's internal numbering -- another summation order in every product -- moves an fp32 residual by more than
+    # the factor 2 allowed here (measured 2.2); leg (ii) runs the default path, numbering included, to the known optimum
+    monkeypatch.setenv("SCS_AMD_REORDER", "0")
     ra, rr = capi.solve(amd, prob, max_iters=iters, **kw), capi.solve(ref, prob, max_iters=iters, **kw)
+    monkeypatch.delenv("SCS_AMD_REORDER")
     ia, ir = ra["info"], rr["info"]
     assert ia["iter"] == ir["iter"] == iters
     scale = max(1.0, abs(ir["pobj"]), abs(ir["dobj"]))
