@@ -1537,7 +1537,8 @@ scs_int scs_amd_get_spmv_kernel_name(const ScsWork *w, scs_int which, char *buf,
   if (!w) return -1;
   const WaveRowsDev *wv = which ? w->ls.At.wave : w->ls.A.wave;
   char tmp[96];
-  if (wv && wv->built && wv->lockstep) snprintf(tmp, sizeof tmp, "csr_wave_lockstep_kernel<EPI,%d,%d>", wv->ls_wpb, wv->ls_bmode);
+  if (wv && wv->built && wv->wide) snprintf(tmp, sizeof tmp, "csr_wave_wide_kernel<EPI>");
+  else if (wv && wv->built && wv->lockstep) snprintf(tmp, sizeof tmp, "csr_wave_lockstep_kernel<EPI,%d,%d>", wv->ls_wpb, wv->ls_bmode);
   else if (wv && wv->built) snprintf(tmp, sizeof tmp, "csr_wave_kernel<EPI,%d>", wv->pipelined);
   else snprintf(tmp, sizeof tmp, "csr_stream_kernel<EPI>");
   const size_t len = strlen(tmp);

@@ -883,7 +883,9 @@ void LinSys::launch_spmv(int epi, const CsrDev &mat, const real *x, real *y, con
     WaveView v = wd.view();
 #define WR_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
-    if (wd.lockstep) {                                                                                                 \
+    if (wd.wide) {                                                                                                     \
+      hipLaunchKernelGGL((csr_wave_wide_kernel<E>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows);  \
+    } else if (wd.lockstep) {                                                                                          \
       launch_lockstep<E>(wd, g, lds, stream, v, x, y, e, skip);                                                        \
     } else if (wd.pipelined == 1) hipLaunchKernelGGL((csr_wave_kernel<E, 1>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \
     else if (wd.pipelined == 2) hipLaunchKernelGGL((csr_wave_kernel<E, 2>), dim3(g), dim3(WR_BLOCK), lds, stream, v, x, y, e, skip, wd.accrows); \

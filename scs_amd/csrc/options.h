@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 
 namespace scsamd {
@@ -73,6 +74,7 @@ struct OptRow {
   X("box_multi",        OPT_TEST,      1, "0|1",              "force the chip-wide / one-workgroup box-cone Newton iteration") \
   X("vec_max_grid",     OPT_TEST,      1, "g",                "cap on the grid of the vector kernels (tests force grid-striding)") \
   X("spmv_max_grid",    OPT_TEST,      0, "g",                "cap on the grid of the CSR-stream kernel") \
+  X("wr_wide",          OPT_TEST,      0, "0|1",              "force the wide wave layout (column word + 16-bit local rows; the library's choice beyond 2^26 rows or columns)") \
   X("wr_build",         OPT_TEST,      0, "dev|host|verify",  "who builds the wave layout; verify builds both and fails scs_init on any differing byte") \
   X("transpose",        OPT_TEST,      0, "dev|host|verify",  "who builds the pattern transpose; verify as above") \
   X("test_offset_bias", OPT_TEST,      0, "b",                "DLONG build: every stored entry position + b, arrays shifted back (64-bit positions without a 26 GB matrix)") \
@@ -95,10 +97,14 @@ inline const OptRow *opt_find(const char *key) {
   return nullptr;
 }
 
+// Values are INTERNED: every distinct string ever set (or read from the environment) is kept for the life of the process in a
+// node-based container, and the tables map a key to a pointer into it.  A pointer returned by opt_get therefore never dangles, whatever
+// another host thread sets meanwhile (batch runs create workspaces from several threads); the pool grows by one short string per
+// distinct value, i.e. by nothing in practice.
 struct OptState {
   std::mutex mu;
-  std::map<std::string, std::string> set; // programmatic values
-  std::map<std::string, std::string> env; // environment fallbacks as last read (stable storage for the returned pointers)
+  std::set<std::string> pool;                // interned values (std::set never moves its elements)
+  std::map<std::string, const char *> set;   // programmatic values
 };
 inline OptState &opt_state() {
   static OptState s;
@@ -110,19 +116,19 @@ inline int opt_set(const char *key, const char *value) {
   if (!key || !opt_find(key)) return -1;
   OptState &s = opt_state();
   std::lock_guard<std::mutex> g(s.mu);
-  if (value) s.set[key] = value;
+  if (value) s.set[key] = s.pool.insert(value).first->c_str();
   else s.set.erase(key);
   return 0;
 }
 
-// the value in force, or NULL when the option is at its default.  The returned pointer stays valid until the same key is set again.
+// the value in force, or NULL when the option is at its default.  The returned pointer stays valid for the life of the process.
 inline const char *opt_get(const char *key) {
   const OptRow *row = opt_find(key);
   if (!row) return nullptr; // unknown keys never reach the environment (tests/test_options.py keeps the table complete)
   OptState &s = opt_state();
   std::lock_guard<std::mutex> g(s.mu);
   auto it = s.set.find(key);
-  if (it != s.set.end()) return it->second.c_str();
+  if (it != s.set.end()) return it->second;
   if (row->cls == OPT_AB || row->cls == OPT_TEST) {
     const char *allow = getenv("SCS_AMD_ALLOW_ENV_HOOKS");
     if (!allow || !atoi(allow)) return nullptr;
@@ -131,9 +137,7 @@ inline const char *opt_get(const char *key) {
   for (const char *c = key; *c; ++c) name += (char)((*c >= 'a' && *c <= 'z') ? *c - 'a' + 'A' : *c);
   const char *e = getenv(name.c_str());
   if (!e) return nullptr;
-  std::string &slot = s.env[key];
-  if (slot != e) slot = e;
-  return slot.c_str();
+  return s.pool.insert(e).first->c_str(); // (the environment's own storage may be rewritten by setenv / putenv: a copy is returned)
 }
 inline bool opt_is_set(const char *key) { return opt_get(key) != nullptr; }
 

@@ -39,8 +39,9 @@ struct WaveView {
   int rows, nunit, cbits, cols;
   const int *urow;     // nunit + 1 : first row of each unit
   const eoff *useg;    // 2 * nunit : [first entry (4-aligned), one past the last entry] of each unit (entry positions: eoff)
-  const unsigned *wrd; // nnz : column | local row << cbits
+  const unsigned *wrd; // nnz : column | local row << cbits  (wide layout: the column alone)
   const real *val;     // nnz
+  const unsigned short *rowl; // wide layout only (gathered vectors beyond 2^26 entries, round 6): the local row of every entry; else null
 };
 
 #ifdef __HIPCC__
@@ -184,6 +185,45 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
   }
   if ((EPI == EPI_GP || EPI == EPI_GP3) && e.partial) wr_block_partials<EPI, WR_WPB>(e, red, dot, d1, d2, wave, lane);
 }
+// WIDE layout (round 6): a gathered vector of more than 2^26 entries leaves no room for the local row in the 32-bit packed word (the run with
+// nnz = 2.2e9, n = 1e8, m = 2e8 fell back to csr_stream_kernel at 0.085 of the byte roofline for that reason, profiles/r6_dlong_real.json).
+// The word then holds the column alone and the local row travels in a 16-bit array of its own: 14 B per entry instead of 12, the same
+// wave-owned rows, LDS accumulators, bucket order and epilogues.  The plain schedule only (PIPE = 0; no lockstep): the same entry order and
+// the same sums, bit for bit, as csr_wave_kernel<EPI, 0> on the narrow layout of the same matrix (tests force it at small sizes, option wr_wide).
+template <int EPI>
+__global__ __launch_bounds__(WR_BLOCK) void csr_wave_wide_kernel(WaveView A, const real *__restrict__ x, real *y, EpiArgs e, const int *skip,
+                                                                 int accrows) {
+  if (skip && *skip) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wr_smem[];
+  __shared__ real red[3][WR_WPB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  real *acc = reinterpret_cast<real *>(wr_smem) + (size_t)wave * accrows;
+  real dot = 0, d1 = 0, d2 = 0;
+  for (int u = blockIdx.x * WR_WPB + wave; u < A.nunit; u += gridDim.x * WR_WPB) {
+    const int r0 = A.urow[u], nr = A.urow[u + 1] - r0;
+    const eoff s = A.useg[2 * u], t = A.useg[2 * u + 1];
+    for (int k = lane; k < nr; k += 64) acc[k] = 0;
+    for (eoff e0 = s; e0 < t; e0 += 256) {
+      const eoff eb = e0 + lane * 4;
+      const WrChunk c = wr_load(A, eb);
+      const uint2 rr = *reinterpret_cast<const uint2 *>(A.rowl + eb); // four 16-bit local rows (unit starts are 4-aligned: 8-byte aligned)
+      const unsigned w[4] = {c.w.x, c.w.y, c.w.z, c.w.w};
+      const unsigned lr[4] = {rr.x & 0xffffu, rr.x >> 16, rr.y & 0xffffu, rr.y >> 16};
+      real xx[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xx[i] = eb + i < t ? x[w[i]] : (real)0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (eb + i < t) lds_add(acc + lr[i], c.v[i] * xx[i]);
+    }
+    for (int k = lane; k < nr; k += 64) {
+      const real a = epi_init<EPI>(e, y, r0 + k) + acc[k];
+      if (EPI == EPI_GP3) epi_apply3(e, y, r0 + k, a, dot, d1, d2);
+      else epi_apply<EPI>(e, y, r0 + k, a, dot);
+    }
+  }
+  if ((EPI == EPI_GP || EPI == EPI_GP3) && e.partial) wr_block_partials<EPI, WR_WPB>(e, red, dot, d1, d2, wave, lane);
+}
 // Lockstep instantiation (round 4; the library's choice for fp64 systems from 5e6 nonzeros on, SCS_AMD_WR_LOCKSTEP = 0 | 1 forces either): ONE
 // workgroup of 16 waves per CU, one unit per wave (units half as long as the plain kernel's).  The host stores every 256-entry chunk so that
 // gather instruction i of a wave covers the i-th QUARTER of the chunk's column window (rank r of the chunk's entries in column order sits at
@@ -277,7 +317,12 @@ struct WaveRowsDev {
   long long bias = 0; // test hook of the DLONG build (CsrDev::bias): entry positions stored +bias, arrays handed over shifted by -bias
   DevBuf<unsigned> wrd;
   DevBuf<real> val;
-  WaveView view() const { return WaveView{rows, nunit, cbits, cols, urow.p, useg.p, wrd.p - bias, val.p - bias}; }
+  bool wide = false;            // gathered vector beyond 2^26 entries (or option wr_wide): column word + 16-bit local rows (csr_wave_wide_kernel)
+  DevBuf<unsigned short> rowl;  // wide layout only
+  WaveView view() const { return WaveView{rows, nunit, cbits, cols, urow.p, useg.p, wrd.p - bias, val.p - bias, wide ? rowl.p - bias : nullptr}; }
+  // distinct 128-byte lines per unit are COUNTED (a bitmap over the gathered vector's lines, in LDS on the device) only while that bitmap is
+  // small; beyond, both builders report one line per entry (the count only picks the stream flavour)
+  static bool lines_counted(int cols) { return ((long long)cols >> (sizeof(real) == 8 ? 4 : 5)) / 8 <= 64 * 1024; }
   // every workgroup must be resident at once (8 waves per CU): a wave then walks its units one after the
   // other and all waves restart at column 0 together, which keeps the gather window of x aligned; a second
   // generation of workgroups starting at column 0 while the first is half way through thrashes L2 instead
@@ -300,7 +345,7 @@ struct WaveRowsDev {
   // column): nnz 5e5 23.5 / 23.5, 1e6 30.0 / 32.7, 1.5e6 34.8 / 38.5, 2e6 39.3 / 43.3, 4e6 61.3 / 76.5 -- no
   // barriers and no product staging pay even while the gathered vector still fits an XCD's L2
   static bool wanted(int cols, const eoff *hptr, int rows) {
-    if (col_bits(cols) > 26) return false; // packed word: column bits + at least 6 row bits
+    // (beyond 26 column bits the packed word has no room for the local row: the wide layout, round 6)
     if (const char *e = opt_get("waverows")) return atoi(e) != 0; // tests force either path
     return (long long)hptr[rows] >= 1000000LL;
   }
@@ -320,7 +365,9 @@ struct WaveRowsDev {
     rows = rows_;
     cols = cols_;
     cbits = col_bits(cols);
-    const int rows_cap = (int)std::min<long long>(WR_ROWS_MAX, 1ll << (32 - cbits));
+    wide = cbits > 26;
+    if (const char *e = opt_get("wr_wide")) wide = wide || atoi(e) != 0; // tests force the wide layout at small sizes
+    const int rows_cap = wide ? WR_ROWS_MAX : (int)std::min<long long>(WR_ROWS_MAX, 1ll << (32 - cbits));
     nnz_all = hptr[rows];
     // nonzero budget per unit: ~8 waves per CU on the whole chip (SCS_AMD_WR_NNZ overrides)
     int dev = 0;
@@ -342,9 +389,13 @@ struct WaveRowsDev {
     if (const char *w = opt_get("wr_ls_wpb")) ls_wpb = atoi(w) == 8 ? 8 : 16;
     if (const char *b = opt_get("wr_ls_barriers")) ls_bmode = atoi(b) == 1 ? 1 : 4;
     if (const char *o = opt_get("wr_ls_order")) sub_window_order = atoi(o) != 0; // measurements: lockstep without the quarter-window chunk order
+    if (wide) lockstep = sub_window_order = 0; // the wide layout runs the plain schedule only
     if (lockstep) wpc = ls_wpb; // one workgroup per CU, one unit per wave
     if (const char *e = opt_get("wr_wpc")) wpc = std::max(1, std::min(32, atoi(e)));
     long long budget = std::max<long long>(1024, (nnz_all + (long long)wpc * cus - 1) / ((long long)wpc * cus));
+    // wide layout = huge matrices: units short enough for the device builder's in-LDS sort (8192 entries), whatever the resident wave count
+    // (at nnz = 2e9 the host builder would walk every entry on one thread, and the walk of a wave over many units costs nothing there)
+    if (wide) budget = std::min<long long>(budget, 8192 - 64);
     if (const char *e = opt_get("wr_nnz")) budget = std::max(64, atoi(e));
     auto partition = [&](long long bud) {
       ur.clear();
@@ -397,14 +448,20 @@ struct WaveRowsDev {
     lines_per_entry = nnz_all > 0 ? (double)distinct / (double)nnz_all : 1.0;
     pipelined = lines_per_entry < 0.8 ? 1 : 0;
     if (const char *e = opt_get("wr_pipe")) pipelined = std::max(0, std::min(2, atoi(e))); // tests / measurements force 0 | 1 | 2 (two chunks per trip)
+    if (wide) pipelined = 0;
     // lockstep: a barrier in front of every gather instruction when every gather is its own line, one per chunk when a unit's
     // gathers share lines anyway (band of 1024 rows at the headline sizes: 34.0 vs 35.3 us per product; uniformly random: 65.1 vs 62.2)
     if (ls_bmode < 0) ls_bmode = lines_per_entry < 0.3 ? 1 : 4;
     built = true;
   }
-  void fill_host(const eoff *hptr, const int *hidx, const real *hval, std::vector<unsigned> &hw, std::vector<real> &hv, long long &distinct_total) {
+  void fill_host(const eoff *hptr, const int *hidx, const real *hval, std::vector<unsigned> &hw, std::vector<real> &hv, long long &distinct_total,
+                 std::vector<unsigned short> *hr = nullptr) {
     hw.assign(cap, 0u);
     hv.assign(cap, (real)0);
+    if (wide) {
+      if (!hr) throw HipError("scs_amd: the wide wave layout needs the local-row array");
+      hr->assign(cap, (unsigned short)0);
+    }
     // stable counting sort of every unit by column bucket (ordering is a locality heuristic: any
     // order gives the same sums up to rounding)
     std::vector<int> cnt(WR_BUCKETS + 1);
@@ -417,7 +474,12 @@ struct WaveRowsDev {
       for (int rr = ur[u]; rr < ur[u + 1]; ++rr)
         for (eoff k = hptr[rr]; k < hptr[rr + 1]; ++k) {
           const size_t qq = base + cnt[hidx[k] >> bshift]++;
-          hw[qq] = (unsigned)hidx[k] | ((unsigned)(rr - ur[u]) << cbits);
+          if (wide) {
+            hw[qq] = (unsigned)hidx[k];
+            (*hr)[qq] = (unsigned short)(rr - ur[u]);
+          } else {
+            hw[qq] = (unsigned)hidx[k] | ((unsigned)(rr - ur[u]) << cbits);
+          }
           hv[qq] = hval[k];
         }
     }
@@ -450,7 +512,9 @@ struct WaveRowsDev {
         }
       }
     }
-    { // column locality: how many distinct lines of the gathered vector does a unit touch per entry?
+    if (!lines_counted(cols)) {
+      distinct_total = nnz_all;
+    } else { // column locality: how many distinct lines of the gathered vector does a unit touch per entry?
       const int lshift = sizeof(real) == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
       std::vector<int> stamp(((size_t)cols >> lshift) + 2, -1);
       long long distinct = 0;
@@ -470,6 +534,7 @@ struct WaveRowsDev {
     useg.alloc(us.size());
     wrd.alloc(cap); // zero-filled: the gaps between units and the tail hold zeros
     val.alloc(cap);
+    if (wide) rowl.alloc(cap);
     urow.upload(ur.data(), ur.size(), st);
     useg.upload(us.data(), us.size(), st);
   }
@@ -479,10 +544,12 @@ struct WaveRowsDev {
     std::vector<unsigned> hw;
     std::vector<real> hv;
     long long distinct = 0;
-    fill_host(hptr, hidx, hval, hw, hv, distinct);
+    std::vector<unsigned short> hr;
+    fill_host(hptr, hidx, hval, hw, hv, distinct, &hr);
     alloc_and_upload_plan(st);
     wrd.upload(hw.data(), cap, st);
     val.upload(hv.data(), cap, st);
+    if (wide) rowl.upload(hr.data(), cap, st);
     HIP_CHECK(hipStreamSynchronize(st));
     finish(distinct);
   }

@@ -64,7 +64,8 @@ template <bool SUBWIN>
 __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const eoff *__restrict__ ptr, const int *__restrict__ idx,
                                                             const real *__restrict__ val, const int *__restrict__ urow,
                                                             const eoff *__restrict__ useg, unsigned *wrd, real *vout, int cbits,
-                                                            int bshift, int lshift, int bm_words, unsigned long long *distinct) {
+                                                            int bshift, int lshift, int bm_words, unsigned long long *distinct,
+                                                            unsigned short *rowl_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wb_smem[];
   unsigned long long *key64 = reinterpret_cast<unsigned long long *>(wb_smem);
   unsigned *key32 = reinterpret_cast<unsigned *>(wb_smem);
@@ -86,8 +87,10 @@ __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const eoff *__restri
     if (t < len) {
       const unsigned col = (unsigned)idx[k0 + t];
       key32[t] = ((col >> bshift) << 13) | (unsigned)t;
-      const unsigned line = col >> lshift;
-      atomicOr(&bm[line >> 5], 1u << (line & 31));
+      if (bm_words > 0) { // (beyond WaveRowsDev::lines_counted the lines are not counted: one per entry is reported)
+        const unsigned line = col >> lshift;
+        atomicOr(&bm[line >> 5], 1u << (line & 31));
+      }
     } else {
       key32[t] = 0xFFFFFFFFu;
     }
@@ -103,13 +106,18 @@ __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const eoff *__restri
     if (tid == 0) {
       unsigned tot = 0;
       for (int w = 0; w < WB_THREADS / 64; ++w) tot += red[w];
-      atomicAdd(distinct, (unsigned long long)tot);
+      atomicAdd(distinct, bm_words > 0 ? (unsigned long long)tot : (unsigned long long)len);
     }
   }
   if (!SUBWIN) {
     for (int r = tid; r < len; r += WB_THREADS) {
       const int t = (int)(key32[r] & 8191u);
-      wrd[base + r] = (unsigned)idx[k0 + t] | ((unsigned)rowl[t] << cbits);
+      if (rowl_out) { // wide layout: the column alone, the local row in its own array
+        wrd[base + r] = (unsigned)idx[k0 + t];
+        rowl_out[base + r] = rowl[t];
+      } else {
+        wrd[base + r] = (unsigned)idx[k0 + t] | ((unsigned)rowl[t] << cbits);
+      }
       vout[base + r] = val[k0 + t];
     }
     return;
@@ -148,7 +156,8 @@ __global__ __launch_bounds__(WB_THREADS) void k_wave_layout(const eoff *__restri
 inline bool wave_fill_dev(WaveRowsDev &w, const eoff *d_ptr, const int *d_idx, const real *d_val, hipStream_t st, long long &distinct) {
   const int lshift = sizeof(real) == 8 ? 4 : 5; // 128-byte line = 16 fp64 / 32 fp32 entries
   const long long lines = ((long long)w.cols >> lshift) + 1;
-  const int bm_words = (int)((lines + 31) / 32);
+  const int bm_words = WaveRowsDev::lines_counted(w.cols) ? (int)((lines + 31) / 32) : 0;
+  if (w.wide && w.sub_window_order) return false; // (never planned: the wide layout runs the plain schedule)
   const size_t lds = WB_LDS_KEYS + WB_LDS_ROWL + (size_t)bm_words * 4;
   if (w.max_unit_entries() > WR_DEV_UNIT_MAX || lds > WB_LDS_MAX || w.nunit < 1) return false;
   // the limit that counts is the device's opt-in LDS per workgroup (queried, not assumed), and the kernel's static LDS
@@ -168,7 +177,7 @@ inline bool wave_fill_dev(WaveRowsDev &w, const eoff *d_ptr, const int *d_idx, c
   DevBuf<unsigned long long> cnt(1);
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(w.nunit), dim3(WB_THREADS), lds, st, d_ptr, d_idx, d_val, (const int *)w.urow.p, (const eoff *)w.useg.p,
-                       w.wrd.p, w.val.p, w.cbits, w.bshift, lshift, bm_words, cnt.p);
+                       w.wrd.p, w.val.p, w.cbits, w.bshift, lshift, bm_words, cnt.p, w.wide ? w.rowl.p : (unsigned short *)nullptr);
   };
   if (w.sub_window_order) launch(k_wave_layout<true>);
   else launch(k_wave_layout<false>);
@@ -212,18 +221,23 @@ inline void wave_build(WaveRowsDev &w, int rows, int cols, const eoff *hptr, con
       HIP_CHECK(hipStreamSynchronize(st));
     }
     long long dh = 0;
-    w.fill_host(hptr, hidx, hval, hw, hv, dh);
+    std::vector<unsigned short> hr;
+    w.fill_host(hptr, hidx, hval, hw, hv, dh, &hr);
     if (on_dev) { // verify
       std::vector<unsigned> gw(w.cap);
       std::vector<real> gv(w.cap);
+      std::vector<unsigned short> gr(w.wide ? w.cap : 0);
       w.wrd.download(gw.data(), w.cap, st);
       w.val.download(gv.data(), w.cap, st);
+      if (w.wide) w.rowl.download(gr.data(), w.cap, st);
       HIP_CHECK(hipStreamSynchronize(st));
-      if (dh != distinct || memcmp(gw.data(), hw.data(), w.cap * sizeof(unsigned)) != 0 || memcmp(gv.data(), hv.data(), w.cap * sizeof(real)) != 0)
+      if (dh != distinct || memcmp(gw.data(), hw.data(), w.cap * sizeof(unsigned)) != 0 || memcmp(gv.data(), hv.data(), w.cap * sizeof(real)) != 0 ||
+          (w.wide && memcmp(gr.data(), hr.data(), w.cap * sizeof(unsigned short)) != 0))
         throw HipError("scs_amd: device-built wave-rows layout differs from the host builder's (SCS_AMD_WR_BUILD=verify)");
     } else {
       w.wrd.upload(hw.data(), w.cap, st);
       w.val.upload(hv.data(), w.cap, st);
+      if (w.wide) w.rowl.upload(hr.data(), w.cap, st);
       HIP_CHECK(hipStreamSynchronize(st));
       distinct = dh;
     }

@@ -324,3 +324,49 @@ def test_three_kernel_cg_iteration_matches_the_four_kernel_one_and_the_reference
         wr, xr = _solve_with(ref, prob.matA, prob.matP if with_p else None, dr, b, s, 1e-12)
         ref.scs_free_lin_sys_work(wr)
         assert np.abs(res[1e-12, "1"][0] - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize("libname", ["libscsamd_linsys.so", "libscsamd_f32.so"])
+def test_wide_wave_layout_equals_the_narrow_one_bit_for_bit(libname, monkeypatch):
+    """Round 6: beyond 2^26 rows or columns the 32-bit packed word has no room for the local row; the WIDE layout keeps the column in
+    the word and the local row in a 16-bit array of its own (csr_wave_wide_kernel, spmv_wave.h) -- found by the nnz = 2.2e9 run, which
+    had fallen back to the CSR-stream kernel.  Forced here at a small size (option wr_wide): both builders agree byte for byte (verify
+    mode), and a linear solve through it returns the SAME BITS as csr_wave_kernel<EPI, 0> on the narrow layout (same entry order, same
+    adds) and the reference's answer; ragged units and a few long rows included."""
+    import scipy.sparse as sp
+    amd = capi.load(libname)
+    T = amd._scs_types
+    n, m = 30000, 70001
+    A = probgen.random_csc(m - 40, n, 9, seed=23)
+    dense = sp.random(40, n, density=0.05, random_state=5, format="csc")
+    A = sp.vstack([A, dense]).tocsc()
+    A.sort_indices()
+    prob = capi.Problem(A, np.zeros(m), np.zeros(n), dict(l=m), T=T)
+    f = T.np_float
+    dr = probgen.diag_r(n, m, z=m // 10).astype(f)
+    rng = np.random.default_rng(6)
+    b = rng.uniform(-1, 1, n + m).astype(f)
+    s = (rng.uniform(-1, 1, n) * 0.1).astype(f)
+    tol = 1e-12 if f is np.float64 else 1e-5
+    monkeypatch.setenv("SCS_AMD_WAVEROWS", "1")
+    monkeypatch.setenv("SCS_AMD_WR_LOCKSTEP", "0")
+    monkeypatch.setenv("SCS_AMD_WR_PIPE", "0")
+    monkeypatch.setenv("SCS_AMD_WR_BUILD", "verify")
+    outs = {}
+    for wide, unit_nnz in (("0", "1500"), ("1", "1500"), ("0", "300"), ("1", "300")):
+        monkeypatch.setenv("SCS_AMD_WR_WIDE", wide)
+        monkeypatch.setenv("SCS_AMD_WR_NNZ", unit_nnz)
+        w = amd.scs_init_lin_sys_work(C.byref(prob.matA), None, dr.ctypes.data_as(T.fp))
+        assert w, (wide, unit_nnz)
+        out = b.copy()
+        assert amd.scs_solve_lin_sys(w, out.ctypes.data_as(T.fp), s.ctypes.data_as(T.fp), tol) == 0
+        amd.scs_free_lin_sys_work(w)
+        outs[(wide, unit_nnz)] = out
+    assert np.array_equal(outs[("0", "1500")], outs[("1", "1500")])
+    assert np.array_equal(outs[("0", "300")], outs[("1", "300")])
+    assert np.abs(outs[("1", "1500")]).max() > 0
+    if f is np.float64:
+        ref = _ref()
+        wr, xr = _solve_with(ref, prob.matA, None, dr, b, s, 1e-12)
+        ref.scs_free_lin_sys_work(wr)
+        assert np.abs(outs[("1", "1500")] - xr).max() <= 1e-8 * np.abs(xr).max()
