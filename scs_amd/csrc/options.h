@@ -74,7 +74,7 @@ struct OptRow {
   X("box_multi",        OPT_TEST,      1, "0|1",              "force the chip-wide / one-workgroup box-cone Newton iteration") \
   X("vec_max_grid",     OPT_TEST,      1, "g",                "cap on the grid of the vector kernels (tests force grid-striding)") \
   X("spmv_max_grid",    OPT_TEST,      0, "g",                "cap on the grid of the CSR-stream kernel") \
-  X("wr_wide",          OPT_TEST,      0, "0|1",              "force the wide wave layout (column word + 16-bit local rows; the library's choice beyond 2^26 rows or columns)") \
+  X("wr_wide",          OPT_TEST,      0, "0|1",              "the wide wave layout (column word + 16-bit local rows): forced at any size (tests), and the only way to get a wave layout beyond 2^26 rows or columns (default there: CSR-stream kernel, same speed, 61 GB less HBM at nnz = 2.2e9)") \
   X("wr_build",         OPT_TEST,      0, "dev|host|verify",  "who builds the wave layout; verify builds both and fails scs_init on any differing byte") \
   X("transpose",        OPT_TEST,      0, "dev|host|verify",  "who builds the pattern transpose; verify as above") \
   X("test_offset_bias", OPT_TEST,      0, "b",                "DLONG build: every stored entry position + b, arrays shifted back (64-bit positions without a 26 GB matrix)") \

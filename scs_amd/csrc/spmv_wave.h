@@ -186,7 +186,8 @@ __global__ __launch_bounds__(WR_BLOCK) void csr_wave_kernel(WaveView A, const re
   if ((EPI == EPI_GP || EPI == EPI_GP3) && e.partial) wr_block_partials<EPI, WR_WPB>(e, red, dot, d1, d2, wave, lane);
 }
 // WIDE layout (round 6): a gathered vector of more than 2^26 entries leaves no room for the local row in the 32-bit packed word (the run with
-// nnz = 2.2e9, n = 1e8, m = 2e8 fell back to csr_stream_kernel at 0.085 of the byte roofline for that reason, profiles/r6_dlong_real.json).
+// nnz = 2.2e9, n = 1e8, m = 2e8 fell back to csr_stream_kernel at 0.085 of the byte roofline, profiles/r6_dlong_real.json -- and so did
+// this layout when it was built: 0.086; see WaveRowsDev::wanted).
 // The word then holds the column alone and the local row travels in a 16-bit array of its own: 14 B per entry instead of 12, the same
 // wave-owned rows, LDS accumulators, bucket order and epilogues.  The plain schedule only (PIPE = 0; no lockstep): the same entry order and
 // the same sums, bit for bit, as csr_wave_kernel<EPI, 0> on the narrow layout of the same matrix (tests force it at small sizes, option wr_wide).
@@ -345,7 +346,14 @@ struct WaveRowsDev {
   // column): nnz 5e5 23.5 / 23.5, 1e6 30.0 / 32.7, 1.5e6 34.8 / 38.5, 2e6 39.3 / 43.3, 4e6 61.3 / 76.5 -- no
   // barriers and no product staging pay even while the gathered vector still fits an XCD's L2
   static bool wanted(int cols, const eoff *hptr, int rows) {
-    // (beyond 26 column bits the packed word has no room for the local row: the wide layout, round 6)
+    // Beyond 26 column bits the packed word has no room for the local row.  The WIDE layout (round 6) handles that, but is NOT chosen by
+    // default: measured on the nnz = 2.2e9 problem (n = 1e8, m = 2e8) it times exactly like the CSR-stream kernel -- 42.9 vs 43.0 ms per
+    // product, both at one HBM line per gather (2.2e9 x 128 B = 282 GB per product at 6.7 TB/s: at that size no window of the gathered
+    // vector stays in any cache) -- for 61 GB more HBM (profiles/r6_dlong_real.json).  Option wr_wide = 1 selects it.
+    if (col_bits(cols) > 26) {
+      const char *w = opt_get("wr_wide");
+      if (!w || !atoi(w)) return false;
+    }
     if (const char *e = opt_get("waverows")) return atoi(e) != 0; // tests force either path
     return (long long)hptr[rows] >= 1000000LL;
   }
