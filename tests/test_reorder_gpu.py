@@ -133,7 +133,8 @@ def _session(lib, prob, b2, c2, warm0, exact, **over):
     return out
 
 
-def test_renumbered_solve_warm_start_and_update_match_the_reference_exact_cg(monkeypatch):
+@pytest.mark.parametrize("family", ["scrambled_band", "uniformly_random"])
+def test_renumbered_solve_warm_start_and_update_match_the_reference_exact_cg(monkeypatch, family):
     """the renumbering maps b, c, warm starts, scs_update vectors and (x, y, s) across the API
     boundary; the tests above compare the library with itself.  Here the REFERENCE (oracle/_ref exactcg flavour: every linear
     system to the 1e-12 floor, include/glbopts.h:253-255 hook) solves a scrambled banded SOCP with mixed zero / nonnegative /
@@ -146,7 +147,10 @@ def test_renumbered_solve_warm_start_and_update_match_the_reference_exact_cg(mon
     ref = pyoracle.load_ref("libscsindir_ref_exactcg.so")
     lib = capi.load("libscsamd.so")
     n, m = 40000, 80000
-    scr = problems.scramble_prob(problems.random_socp(n, m, 10, seed=23, band=BAND), 5)
+    if family == "scrambled_band":   # hidden locality: recovered by the anchors / Cuthill-McKee numberings of round 4
+        scr = problems.scramble_prob(problems.random_socp(n, m, 10, seed=23, band=BAND), 5)
+    else:                            # round 6: no locality to recover -> chain + home numbering, which also PERMUTES THE TAILS of the
+        scr = problems.random_socp(n, m, 10, seed=24)  # second-order cones (every row but the cone's first): y and s must come back in place
     assert scr["cone"]["z"] > 0 and scr["cone"]["l"] > 0 and len(scr["cone"]["q"]) > 2
     prob = capi.Problem(scr["A"], scr["b"], scr["c"], scr["cone"])
     rng = np.random.default_rng(5)
@@ -157,7 +161,16 @@ def test_renumbered_solve_warm_start_and_update_match_the_reference_exact_cg(mon
     want = _session(ref, prob, b2, c2, warm0, exact=False, **over)
     monkeypatch.setenv("SCS_AMD_REORDER", "1")  # forced: 4e5 nonzeros is below the library's own threshold
     info = _reorder_info(lib, prob)
-    assert info[0] == 1.0 and 0.5 * (info[3] + info[4]) < 0.25 * (info[1] + info[2]), info
+    assert info[0] == 1.0, info
+    if family == "scrambled_band":
+        assert 0.5 * (info[3] + info[4]) < 0.25 * (info[1] + info[2]), info
+    else:
+        assert 0.5 * (info[3] + info[4]) < 0.85 * 0.5 * (info[1] + info[2]), info
+        T = lib._scs_types
+        cp, rp = np.zeros(prob.n, dtype=T.np_int), np.zeros(prob.m, dtype=T.np_int)
+        assert lib.scs_amd_plan_reorder(C.byref(prob.matA), C.byref(prob.k), cp.ctypes.data_as(T.ip), rp.ctypes.data_as(T.ip), None) == 1
+        o = scr["cone"]["z"] + scr["cone"]["l"]
+        assert np.count_nonzero(rp[o:] != np.arange(o, prob.m)) > 0.5 * (prob.m - o)   # the SOC tails really moved
     got = _session(lib, prob, b2, c2, warm0, exact=True, **over)
     for stage, (g, r) in enumerate(zip(got, want)):
         gi, ri = g["info"], r["info"]
