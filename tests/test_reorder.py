@@ -114,3 +114,47 @@ def test_switch_and_small_problems(monkeypatch):
     assert _plan(big, lib)[0] == 0                              # switched off
     monkeypatch.delenv("SCS_AMD_REORDER", raising=False)
     assert _plan(big, lib)[0] == 1
+
+
+def test_numbering_respects_every_cone_on_random_mixed_cones(monkeypatch):
+    """Fuzz of the decision with the attempt forced (small, dense, ragged problems; empty rows and columns happen): whatever
+    candidate is kept, the result is a pair of permutations in which zero / nonnegative rows stay inside their cones, a second-order
+    cone keeps its rows and its FIRST row, and box, PSD, exponential and power rows do not move at all (include/scs.h:121-172)."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SCS_AMD_REORDER", "1")
+    lib = capi.load("libscsamd.so")
+    T = lib._scs_types
+    rng = np.random.default_rng(0)
+    kept = 0
+    for trial in range(60):
+        z, l = int(rng.integers(0, 50)), int(rng.integers(0, 80))
+        nb = int(rng.integers(0, 3)) * int(rng.integers(1, 20))
+        q = [int(v) for v in rng.integers(1, 40, size=rng.integers(0, 12))]
+        s_ = [int(v) for v in rng.integers(1, 6, size=rng.integers(0, 3))]
+        cone = dict(z=z, l=l, q=q, s=s_, ep=int(rng.integers(0, 3)), ed=int(rng.integers(0, 2)))
+        if nb:
+            cone.update(bu=np.ones(nb), bl=-np.ones(nb))
+        m = capi.cone_rows(cone)
+        if m < 4:
+            continue
+        n = int(rng.integers(3, 120))
+        A = sp.random(m, n, density=rng.uniform(0.02, 0.3), random_state=int(rng.integers(1 << 30)), format="csc")
+        prob = capi.Problem(A, np.zeros(m), np.zeros(n), cone)
+        cp, rp = np.zeros(n, dtype=T.np_int), np.zeros(m, dtype=T.np_int)
+        rc = lib.scs_amd_plan_reorder(C.byref(prob.matA), C.byref(prob.k), cp.ctypes.data_as(T.ip), rp.ctypes.data_as(T.ip), None)
+        assert rc in (0, 1)
+        kept += rc
+        assert sorted(cp) == list(range(n)) and sorted(rp) == list(range(m)), trial
+        o = 0
+        assert set(rp[o:o + z]) == set(range(o, o + z))
+        o += z
+        assert set(rp[o:o + l]) == set(range(o, o + l))
+        o += l
+        bs = nb + 1 if nb else 0
+        assert np.array_equal(rp[o:o + bs], np.arange(o, o + bs))
+        o += bs
+        for qi in q:
+            assert rp[o] == o and set(rp[o:o + qi]) == set(range(o, o + qi)), (trial, "second-order cone")
+            o += qi
+        assert np.array_equal(rp[o:], np.arange(o, m)), (trial, "PSD / exponential / power rows moved")
+    assert kept > 10
