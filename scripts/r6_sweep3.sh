@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${1:-sweep3}
 mkdir -p $OUT
 cd $R
-python scripts/bench_spmv_modes.py --cases 1000000:f64:0 --modes ${2:-auto+rh4,auto+rh4+rs32,auto+rh4+rs128,auto+rh4+rs1024,auto+rh4+rb32,auto+rh4+rb8,auto+rh4+rb64+rs64,auto} --iters 30 > $OUT/sweep.jsonl 2> $OUT/sweep.err
+python scripts/bench_spmv_modes.py --cases ${3:-1000000:f64:0} --modes ${2:-auto+rh4,auto+rh4+rs32,auto+rh4+rs128,auto+rh4+rs1024,auto+rh4+rb32,auto+rh4+rb8,auto+rh4+rb64+rs64,auto} --iters 30 > $OUT/sweep.jsonl 2> $OUT/sweep.err
 python - $OUT/sweep.jsonl <<'PY'
 import json,sys
 for l in open(sys.argv[1]):
