@@ -11,7 +11,7 @@ cd $R
 cp scs_amd/lib/libscsamd.so /tmp/lib_shipped.so
 cp scs_amd/lib_var/${3:-psdclk}/libscsamd.so scs_amd/lib/libscsamd.so
 : > $OUT/psd_clocks.md
-for pipe in 1 0; do
+for pipe in ${4:-1 0}; do
   SCS_AMD_PSD_PIPE=$pipe timeout 300 python scripts/bench_sdp.py ${2:-} > $OUT/psdclk_pipe$pipe.log 2>&1
   python - $OUT/psdclk_pipe$pipe.log $pipe >> $OUT/psd_clocks.md <<'PY'
 import sys, re
@@ -29,7 +29,8 @@ if not rows:
 n = len(rows)
 avg = {k: sum(r[k] for r in rows) / n for k in rows[0]}
 tot = avg["unpack_warm"] + avg["fro"] + avg["sweeps"] + avg["tail"]
-print(f"| SCS_AMD_PSD_PIPE={sys.argv[2]} ({'pipelined step' if sys.argv[2]=='1' else 'two-phase step'}) | launches {n} | clocks per launch {tot:.0f} "
+form = {'1': 'pipelined step, look-ahead', '2': 'pipelined step, signal form', '0': 'two-phase step'}[sys.argv[2]]
+print(f"| SCS_AMD_PSD_PIPE={sys.argv[2]} ({form}) | launches {n} | clocks per launch {tot:.0f} "
       f"| unpack+warm {avg['unpack_warm']:.0f} | fro {avg['fro']:.0f} | sweeps {avg['sweeps']:.0f} ({100*avg['sweeps']/tot:.0f} %) | W, WW', pack {avg['tail']:.0f} "
       f"| sweeps per launch {avg['nsweep']:.2f} | steps {avg['steps']:.1f} | rotating steps {avg['rot_steps']:.1f} "
       f"| clocks per rotating step {avg['sweeps']/max(avg['rot_steps'],1):.0f} | {cone[0] if cone else ''} |")

@@ -22,7 +22,7 @@ struct ConeDev {
   // box cone
   DevBuf<real> bl, bu;      // bsize-1 each (already D-normalised, +-inf applied)
   DevBuf<real> box_t;       // [0] Newton warm start (reference c->box_t_warm_start)
-  bool psd_pipe = true;     // pipelined step of k_psd_jacobi (option psd_pipe, read in init)
+  int psd_pipe = 1;         // step of k_psd_jacobi for orders <= 72 (option psd_pipe, read in init): 0 two-phase, 1 look-ahead, 2 signal form
   bool box_multi = false;   // large box: Newton steps as chip-wide launches (k_box_step), else one workgroup (k_box)
   DevBuf<real> box_part, box_ctl;
   // second-order cones

@@ -61,7 +61,7 @@ constexpr int PSD_PIPE_THREADS = PSD_THREADS - 64; // update lanes of the pipeli
 constexpr int PSD_PIPE_VR = 3;
 #endif
 constexpr int PSD_K_LIMIT = 2 * PSD_MAX_PAIRS;
-constexpr size_t PSD_LDS_HEADER = PSD_MAX_PAIRS * (2 * sizeof(real) + 2 * sizeof(int)) + 10 * sizeof(real);
+constexpr size_t PSD_LDS_HEADER = PSD_MAX_PAIRS * (2 * sizeof(real) + 2 * sizeof(int)) + 12 * sizeof(real); // tables, red[8], 4 words of flags (fp32: red + 8 .. red + 11)
 
 // ----------------------------------------------------------------------------
 // Moreau pre / post (cones.c:1567-1593)
@@ -450,7 +450,9 @@ __device__ __forceinline__ PsdRot lane_shift1(const PsdRot &r) {
 
 // PIPE: the pipelined step (round 5) for launches whose largest block leaves room for a second copy of A (order <= PSD_WARM_KMAX);
 // its own instantiation, so that the five-blocks-per-lane update of orders up to 92 does not set this one's register budget
-template <bool PIPE>
+// PIPE = 0: two-phase step; 1: round 5's look-ahead (the next rotations re-derived from the matrix before the step); 2: round 6's signal
+// form (the update lanes own the blocks the next rotations need FIRST and raise a counter; the rotation wave reads the updated entries)
+template <int PIPE>
 __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *__restrict__ psd_off,
                                                             const int *__restrict__ psd_k, real *scratch,
                                                             int kmax, int lds_kmax, int *status, real *vprev,
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   // loads / stores (flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0)) with vector-memory latency on the critical path of EVERY step --
   // rounds 2-4 paid that in the two-phase step too.  Every write and its reads are separated by a workgroup barrier.
   int *rot_any = reinterpret_cast<int *>(red + 8);
-  real *lds_mat = red + 10;
+  real *lds_mat = red + 12;
   const int cone = blockIdx.x, tid = threadIdx.x;
   // psd_k > 0: real symmetric block of that order (packed lower triangle).
   // psd_k < 0: complex Hermitian block of order nn = -psd_k/2 (src/cones.c:1072-1155), handled
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
     __syncthreads();
     // pipelined step: needs a second copy of A (the warm start's T region behind V, dead by now) -> orders up to PSD_WARM_KMAX of a
     // launch whose largest LDS block is that small (the host sizes the LDS for three matrices then); K2 = 2 has a single step
-    const bool pipelined = PIPE && K2 <= PSD_WARM_KMAX && K2 >= 4;
+    const bool pipelined = PIPE != 0 && K2 <= PSD_WARM_KMAX && K2 >= 4;
     const int wave = tid >> 6, lane = tid & 63;
     const bool la = wave == PSD_THREADS / 64 - 1; // the look-ahead wave
     real *A2 = V + (size_t)K2 * ld;
@@ -667,6 +669,89 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       }
       if (la) __builtin_amdgcn_s_setprio(0);
     };
+    // ---- signal form (round 6; psd_lds_step.h): as above, ONE barrier per step and a ping-pong copy of A, but the rotation wave does not
+    // re-derive its entries: the update lanes own the 2 npairs priority blocks as their first items, store them and raise `sig`; the
+    // rotation wave waits for `sig` and reads (a_pq, a_pp, a_qq) of its next pair from the updated copy -- psd_first_rotation's plain
+    // formula on the stored values: the iteration is bit-identical to the two-phase one.
+    auto sweeps_signal = [&](auto nbc) {
+      constexpr int NB = decltype(nbc)::value;
+      PsdItems<NB, 3> items;
+      psd_items_init_priority<NB, 3>(items, tid, PSD_PIPE_THREADS, npairs, K2);
+      int *sig = rot_any + 2; // (header: two flag words, then this counter; `red + 12` starts the matrices)
+      const int npri = psd_priority_count(npairs);
+      const int nsig = (npri < PSD_PIPE_THREADS ? npri + 63 : PSD_PIPE_THREADS + 63) >> 6; // waves whose first items are priority blocks
+      int *my_signal = (!la && wave < nsig && lane == 0) ? sig : nullptr;
+      if (la) __builtin_amdgcn_s_setprio(3);
+      for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+        if (nothing_to_rotate()) break;
+        real offmax = 0;
+        int pos_a = lane, pos_b = K2 - 1 - lane;
+        int la_any = 0, expected = 0;
+        if (tid == 0) *sig = 0; // (the barriers of nothing_to_rotate separate this from the last sweep's reads)
+        if (la) { // prologue: step 0 from the matrix as it stands
+          bool rot = false;
+          if (lane < npairs) {
+            PsdRot r;
+            rot = psd_rotation_now(Acur, pos_a, pos_b, ld, k, thr, offmax, r);
+            psd_pair_advance(lane, K2, pos_a, pos_b);
+            rot_pq[lane] = make_int2(r.x, r.y);
+            rot_cs[lane] = RotCS{r.c, r.s};
+          }
+          la_any = __any(rot ? 1 : 0);
+          if (lane == 0) rot_any[0] = la_any;
+        }
+        __syncthreads();
+        for (int step = 0; step < K2 - 1; ++step) {
+          const int par = step & 1;
+          const int2 *tq = rot_pq + par * PSD_TBL;
+          const RotCS *tc = rot_cs + par * PSD_TBL;
+          real *Anext = Acur == A ? A2 : A;
+          bool rotates;
+          PSD_CLK(clk_a);
+          if (la) {
+            rotates = la_any != 0;
+            if (step + 1 < K2 - 1) {
+              const real *Aread = Acur; // a step that rotates nothing leaves the matrix where it is
+              if (rotates) {
+                expected += nsig;
+                while (__hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expected) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                Aread = Anext;
+              }
+              bool rot = false;
+              if (lane < npairs) {
+                PsdRot r;
+                rot = psd_rotation_now(Aread, pos_a, pos_b, ld, k, thr, offmax, r);
+                psd_pair_advance(lane, K2, pos_a, pos_b);
+                rot_pq[(par ^ 1) * PSD_TBL + lane] = make_int2(r.x, r.y);
+                rot_cs[(par ^ 1) * PSD_TBL + lane] = RotCS{r.c, r.s};
+              }
+              la_any = __any(rot ? 1 : 0);
+              if (lane == 0) rot_any[par ^ 1] = la_any;
+            }
+          } else {
+            rotates = psd_update_pass<NB, 3, true>(Acur, Anext, V, tq, tc, items, ld, rot_any + par, my_signal) != 0;
+          }
+#ifdef SCSAMD_PSD_CLOCKS
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const long long clk_b = clock64();
+#endif
+          __syncthreads();
+#ifdef SCSAMD_PSD_CLOCKS
+          clk_work += clk_b - clk_a;
+          clk_wait += clock64() - clk_b;
+#endif
+          PSD_COUNT(n_steps);
+          if (rotates) {
+            Acur = Anext;
+            PSD_COUNT(n_rot_steps);
+          }
+        }
+        offmax = block_max(offmax, red);
+        if (offmax <= thr) break;
+      }
+      if (la) __builtin_amdgcn_s_setprio(0);
+    };
     // ---- two-phase step (rounds 2-4): rotation parameters on the first npairs lanes, barrier, in-place update, barrier.  Orders
     // 73..92 (no room for a second copy of A) and K2 = 2.
     // round-robin pairing: player 0 fixed, the others rotate -- pair i of step s is (0 or 1 + (i - 1 + s) mod (K2 - 1),
@@ -703,7 +788,12 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
       }
     };
     using std::integral_constant;
-    if (pipelined) {
+    if (pipelined && PIPE == 2) {
+      switch (psd_blocks_per_lane(npairs, PSD_PIPE_THREADS, 3)) {
+      case 1: sweeps_signal(integral_constant<int, 1>()); break;
+      default: sweeps_signal(integral_constant<int, 2>()); break;
+      }
+    } else if (pipelined) {
       switch (psd_blocks_per_lane(npairs, PSD_PIPE_THREADS, PSD_PIPE_VR)) { // blocks of the upper triangle per update lane (K2 <= 72: at most 2)
       case 1: sweeps_pipelined(integral_constant<int, 1>()); break;
       default: sweeps_pipelined(integral_constant<int, 2>()); break;
@@ -803,7 +893,7 @@ __global__ __launch_bounds__(PSD_THREADS) void k_psd_jacobi(real *x, const int *
   if (cone == 0 && (tid & 63) == 0 && (tid == 0 || tid == PSD_THREADS - 64))
     printf("PSDWAVE %s work %lld wait %lld\n", tid == 0 ? "update" : "lookahead", clk_work, clk_wait);
   if (cone == 0 && tid == 0)
-    printf("PSDCLK pipe %d k %d unpack_warm %lld fro %lld sweeps %lld tail %lld nsweep %d steps %d rot_steps %d\n", PIPE ? 1 : 0, k, clk1 - clk0,
+    printf("PSDCLK pipe %d k %d unpack_warm %lld fro %lld sweeps %lld tail %lld nsweep %d steps %d rot_steps %d\n", PIPE, k, clk1 - clk0,
            clk2 - clk1, clk3 - clk2, (long long)clock64() - clk3, sweep, n_steps, n_rot_steps);
 #endif
 }
@@ -994,8 +1084,8 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
     psd_big->init(pk, PSD_LDS_KMAX, stream);
   }
   psd_calls = 0;
-  psd_pipe = true;
-  if (const char *e = opt_get("psd_pipe")) psd_pipe = atoi(e) != 0;
+  psd_pipe = 1;
+  if (const char *e = opt_get("psd_pipe")) psd_pipe = std::max(0, std::min(2, atoi(e)));
   // warm start of the LDS kernel: sized and gated by the largest block that kernel handles (blocks beyond the LDS path
   // carry their own basis in psd_big, and must not switch the small blocks' warm start off)
   psd_vprev.release();
@@ -1053,7 +1143,7 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
     const int K2l = (lds_kmax + 1) & ~1;
     const bool carry = psd_vprev.p != nullptr;
     // round 5: pipelined step (second copy of A in LDS) whenever three matrices fit; SCS_AMD_PSD_PIPE=0 keeps the two-phase step (A/B)
-    const int pipe = (psd_pipe && K2l <= PSD_WARM_KMAX) ? 1 : 0; // psd_pipe: option read in init
+    const int pipe = K2l <= PSD_WARM_KMAX ? psd_pipe : 0; // psd_pipe: option read in init (0 two-phase, 1 look-ahead, 2 signal form)
     const size_t lds = PSD_LDS_HEADER + (size_t)((pipe || (carry && !psd_tscratch.p)) ? 3 : 2) * K2l * (K2l | 1) * sizeof(real);
     const int warm = carry && (psd_calls % PSD_WARM_RESET) != 0;
     ++psd_calls;
@@ -1063,8 +1153,9 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
       hipLaunchKernelGGL(kern, dim3(n_psd), dim3(PSD_THREADS), lds, stream, cw, psd_off.p, psd_k.p, psd_tscratch.p, lds_kmax, lds_kmax,
                          status.p, psd_vprev.p, warm);
     };
-    if (pipe) launch(k_psd_jacobi<true>);
-    else launch(k_psd_jacobi<false>);
+    if (pipe == 2) launch(k_psd_jacobi<2>);
+    else if (pipe == 1) launch(k_psd_jacobi<1>);
+    else launch(k_psd_jacobi<0>);
     if (psd_big) psd_big->project(cw, psd_off.p, psd_k.p, status.p, stream);
   }
   proj_exp_pow(cw);

@@ -49,7 +49,7 @@ struct OptRow {
   X("aa",               OPT_SUPPORTED, 1, "host|dev",         "Anderson acceleration on the host or on the device (default: device when n+m+1 >= 32768)") \
   X("equil",            OPT_SUPPORTED, 0, "host|dev",         "equilibration of scs_init on the host or on the device (default: device when nnz(A) >= 1e5; bit-identical)") \
   X("graph",            OPT_SUPPORTED, 0, "0|1",              "HIP-graph replay of blocks of 8 CG iterations for small systems (default on up to 2e6 nonzeros; 0 is needed under rocprofv3)") \
-  X("psd_pipe",         OPT_SUPPORTED, 1, "0|1",              "pipelined Jacobi step of the LDS PSD kernel for orders <= 72 (default 1; 0 = two-phase step)") \
+  X("psd_pipe",         OPT_SUPPORTED, 1, "0|1|2",            "Jacobi step of the LDS PSD kernel for orders <= 72: 1 (default) = pipelined with a look-ahead wave, 0 = two-phase step, 2 = pipelined in the signal form (the two-phase step's own rotations, one barrier per step; measured slower than 1)") \
   X("waverows",         OPT_SUPPORTED, 1, "0|1",              "wave-owned-rows SpMV layout (default: from 1e6 nonzeros on; 0 = CSR-stream kernel everywhere)") \
   X("psd_cold",         OPT_SUPPORTED, 1, "set",              "no eigenbasis carried between PSD projections (every projection starts cold)") \
   X("wr_lockstep",      OPT_AB,        1, "0|1|2",            "lockstep instantiation of the wave SpMV (default: fp64 from 5e6 nonzeros on); 2 = its chunk order with the plain kernel") \

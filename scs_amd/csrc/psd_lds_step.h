@@ -116,6 +116,70 @@ PSD_HD void psd_items_init(PsdItems<NB, VR> &it, int tid, int nthreads, int npai
   }
 }
 
+// ---- round 6, "signal" form of the pipelined step (k_psd_jacobi<2>) ---------------------------------------------------------------
+// The look-ahead of round 5 RE-DERIVES, from the matrix before step s and step s's rotations, the three entries (a_pq, a_pp, a_qq) its
+// pair of step s + 1 needs -- ~230 instructions of one wave, 1 550 clocks, the bound of the step.  But those entries are among the
+// first things the update itself can produce: pair i of step s + 1 takes its players from pairs i + 1 / i - 1 of step s, so they live
+// in the block (i - 1, i + 1) of step s's block grid ((0, 1) for pair 0, (npairs - 2, npairs - 1) for the last pair) and in the diagonal
+// blocks -- 2 npairs PRIORITY blocks of npairs (npairs + 1) / 2, the same ones in every step because they are named by pair POSITION.
+// In the signal form the update lanes own the priority blocks FIRST (items 0 .. npri - 1: wave 0, and wave 1 from order 66 on), store
+// them, and raise a counter in LDS; the rotation wave waits for the counter and reads its three entries from the updated copy -- the
+// plain rotation of psd_first_rotation, exactly what the two-phase step computes (the signal form is bit-identical to it).
+PSD_HD int psd_priority_count(int npairs) { return npairs >= 3 ? 2 * npairs : (npairs == 2 ? 3 : 1); }
+// item e -> block (P, Q), P <= Q: priority blocks first -- the diagonal (j, j), then (0, 1), (i - 1, i + 1) for i = 1 .. npairs - 2,
+// (npairs - 2, npairs - 1) -- then the others: (P, P + 1) for P = 1 .. npairs - 3, then by distance d = Q - P = 3, 4, ...
+PSD_HD void psd_block_of_item(int e, int npairs, int &P, int &Q) {
+  if (e < npairs) {
+    P = Q = e;
+    return;
+  }
+  if (npairs == 2) { // (0,0), (1,1), (0,1)
+    P = 0;
+    Q = 1;
+    return;
+  }
+  e -= npairs;
+  if (e == 0) {
+    P = 0;
+    Q = 1;
+    return;
+  }
+  if (e <= npairs - 2) { // i = e: (i - 1, i + 1)
+    P = e - 1;
+    Q = e + 1;
+    return;
+  }
+  if (e == npairs - 1) {
+    P = npairs - 2;
+    Q = npairs - 1;
+    return;
+  }
+  e -= npairs;
+  if (e < npairs - 3) { // neighbours (P, P + 1), P = 1 .. npairs - 3
+    P = e + 1;
+    Q = e + 2;
+    return;
+  }
+  e -= npairs - 3 > 0 ? npairs - 3 : 0;
+  int d = 3;
+  while (d < npairs && e >= npairs - d) {
+    e -= npairs - d;
+    ++d;
+  }
+  P = e;
+  Q = e + d;
+}
+template <int NB, int VR>
+PSD_HD void psd_items_init_priority(PsdItems<NB, VR> &it, int tid, int nthreads, int npairs, int K2) {
+  psd_items_init<NB, VR>(it, tid, nthreads, npairs, K2); // the (row, pair) items of V, and okb
+  PSD_UNROLL
+  for (int u = 0; u < NB; ++u) {
+    int P = 0, Q = 0;
+    if (it.okb[u]) psd_block_of_item(tid + u * nthreads, npairs, P, Q);
+    it.bP[u] = P;
+    it.bQ[u] = Q;
+  }
+}
 // where entry (r, c) of the symmetric matrix is stored.  (Device: the 24-bit multiply-add -- orders and leading dimensions are < 100 --
 // is a full-rate instruction; the 32-bit r * ld + c compiles to v_mad_u64_u32, a quarter-rate one, four times per block of the update
 // pass and six times on the look-ahead wave's chain in every step.)
@@ -135,9 +199,13 @@ PSD_HD int psd_sym_index(int r, int c, int ld) {
 // 0 for the loads and skipped by the stores (no per-item branches in the load phase).  A_dst == A_src is the in-place form (every
 // entry is read and written by the same lane); the pipelined step passes the other copy.
 // Returns the flag (1 without one).
-template <int NB, int VR>
+template <int NB, int VR, bool SIG = false>
 PSD_HD int psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair *rot_pq, const RotCS *rot_cs, const PsdItems<NB, VR> &it,
-                           int ld, const int *rotates_flag = nullptr) {
+                           int ld, const int *rotates_flag = nullptr, int *signal = nullptr) {
+  // signal (signal form of the pipelined step, device only): non-null on lane 0 of the waves that own priority blocks -- raised by one
+  // right after the wave's FIRST block (item u = 0: all priority blocks are items u = 0) has been stored.  A wave's LDS instructions
+  // execute in program order, so whoever sees the counter raised sees the stores; the empty asm statements keep the compiler from
+  // moving the stores across the atomic.
   // pipelined step: "does this step rotate at all" is a word in LDS; it is asked for together with the tables (ONE round trip for the
   // flag, the block's two pairs and the row pairs' pair -- left alone the compiler reads the flag, waits, branches, reads the block's
   // tables, waits, reads the rows' table, waits: four dependent round trips per step where two are needed)
@@ -210,6 +278,13 @@ PSD_HD int psd_update_pass(const real *Asrc, real *Adst, real *V, const PsdPair 
         Adst[i21[u]] = c2 * r21 - s2 * r22;
       }
     }
+#ifndef PSD_STEP_HOST_CHECK
+    if (SIG && u == 0) {
+      asm volatile("" ::: "memory");
+      if (signal) __hip_atomic_fetch_add(signal, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+    }
+#endif
   }
   PSD_UNROLL
   for (int j = 0; j < NV; ++j) {
@@ -325,5 +400,15 @@ PSD_HD bool psd_first_rotation(const real *A, int p, int q, int ld, int k, real 
   }
   return psd_make_rotation(apq, app, aqq, p, q, k, thr, offmax, out);
 }
+
+// the rotation of pair (p, q) from the matrix as it stands, its three entries asked for in ONE batch of LDS reads
+PSD_HD bool psd_rotation_now(const real *A, int p, int q, int ld, int k, real thr, real &offmax, PsdRot &out) {
+  real apq = A[psd_sym_index(p, q, ld)], app = A[psd_mad24(p, ld, p)], aqq = A[psd_mad24(q, ld, q)];
+#ifndef PSD_STEP_HOST_CHECK
+  asm volatile("" : "+v"(apq), "+v"(app), "+v"(aqq));
+#endif
+  return psd_make_rotation(apq, app, aqq, p, q, k, thr, offmax, out);
+}
+
 
 } // namespace scsamd

@@ -19,26 +19,50 @@ constexpr int NT_ALL = 512;   // PSD_THREADS
 constexpr int NT_PIPE = 448;  // PSD_THREADS - the look-ahead wave
 
 template <int NB>
-void update_all(const real *As, real *Ad, real *V, const PsdPair *pq, const RotCS *cs, int npairs, int K2, int ld, int nt) {
+void update_all(const real *As, real *Ad, real *V, const PsdPair *pq, const RotCS *cs, int npairs, int K2, int ld, int nt, bool priority) {
   for (int tid = 0; tid < nt; ++tid) {
     PsdItems<NB, 3> it;
-    psd_items_init<NB, 3>(it, tid, nt, npairs, K2);
+    if (priority) psd_items_init_priority<NB, 3>(it, tid, nt, npairs, K2); // the signal form's enumeration: priority blocks first
+    else psd_items_init<NB, 3>(it, tid, nt, npairs, K2);
     psd_update_pass<NB, 3>(As, Ad, V, pq, cs, it, ld);
   }
 }
-void update_dispatch(const real *As, real *Ad, real *V, const PsdPair *pq, const RotCS *cs, int npairs, int K2, int ld, int nt) {
+void update_dispatch(const real *As, real *Ad, real *V, const PsdPair *pq, const RotCS *cs, int npairs, int K2, int ld, int nt,
+                     bool priority = false) {
   switch (psd_blocks_per_lane(npairs, nt)) {
-  case 1: update_all<1>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
-  case 2: update_all<2>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
-  case 3: update_all<3>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
-  default: update_all<4>(As, Ad, V, pq, cs, npairs, K2, ld, nt); break;
+  case 1: update_all<1>(As, Ad, V, pq, cs, npairs, K2, ld, nt, priority); break;
+  case 2: update_all<2>(As, Ad, V, pq, cs, npairs, K2, ld, nt, priority); break;
+  case 3: update_all<3>(As, Ad, V, pq, cs, npairs, K2, ld, nt, priority); break;
+  default: update_all<4>(As, Ad, V, pq, cs, npairs, K2, ld, nt, priority); break;
   }
+}
+// the entries the rotation wave of the signal form reads for pair (p, q) of step s + 1 must lie in PRIORITY blocks of step s (items
+// 0 .. npri - 1 of the enumeration): returns the number of entries that do not
+int priority_misses(const PsdPair *pairs_of_step, int npairs, int p, int q) {
+  auto pair_of = [&](int player) {
+    for (int i = 0; i < npairs; ++i)
+      if (pairs_of_step[i].x == player || pairs_of_step[i].y == player) return i;
+    return -1;
+  };
+  const int P = pair_of(p), Q = pair_of(q);
+  const int npri = psd_priority_count(npairs);
+  auto is_priority = [&](int a, int b) {
+    if (a > b) std::swap(a, b);
+    for (int e = 0; e < npri; ++e) {
+      int bp, bq;
+      psd_block_of_item(e, npairs, bp, bq);
+      if (bp == a && bq == b) return true;
+    }
+    return false;
+  };
+  return (is_priority(P, Q) ? 0 : 1) + (is_priority(P, P) ? 0 : 1) + (is_priority(Q, Q) ? 0 : 1);
 }
 } // namespace
 
 // Jacobi eigen-decomposition of the symmetric k x k matrix `a` (row major) with the kernel's schedule.
 //   pipelined = 0: the two-phase step of rounds 2-4 (parameters, barrier, in-place update, barrier)
 //   pipelined = 1: look-ahead + ping-pong (round 5)
+//   pipelined = 2: signal form (round 6): priority blocks first, the rotation wave reads the updated entries
 // out: evals[k] (diagonal of the rotated matrix), vecs[k*k] (row major, columns = eigenvectors), counters[0] = sweeps,
 // [1] = rotating steps, [2] = steps, [3] = look-ahead source mismatches (must be 0: the players of pair i of step s+1 were found in
 // the pairs the circle-method rule names).  Returns 0, or -1 if the sweep cap was hit.
@@ -85,6 +109,42 @@ extern "C" int psd_check_eig(const double *a, int k, int pipelined, double *eval
         if (!any) continue; // barrier; uniform skip
         ++rsteps;
         update_dispatch(Acur, Acur, V.data(), tq.data(), tc.data(), npairs, K2, ld, NT_ALL); // phase 2, in place
+      }
+    } else if (pipelined == 2) {
+      // signal form (round 6): the update (priority-first enumeration) writes the other copy; the rotation wave reads its three entries
+      // from the UPDATED copy once the priority blocks are stored -- sequentially: after the update
+      bool any = false;
+      for (int i = 0; i < npairs; ++i) {
+        PsdRot r;
+        any |= psd_rotation_now(Acur, pa[i], pb[i], ld, k, thr, offmax, r);
+        psd_pair_advance(i, K2, pa[i], pb[i]);
+        tq[i] = PsdPair{r.x, r.y};
+        tc[i] = RotCS{r.c, r.s};
+      }
+      rot_any[0] = any;
+      for (int step = 0; step < K2 - 1; ++step, ++steps) {
+        const int par = step & 1;
+        const PsdPair *q0 = tq.data() + par * TBL;
+        const RotCS *c0 = tc.data() + par * TBL;
+        const bool rotates = rot_any[par] != 0;
+        if (rotates) {
+          ++rsteps;
+          update_dispatch(Acur, Aoth, V.data(), q0, c0, npairs, K2, ld, NT_PIPE, true);
+        }
+        if (step + 1 < K2 - 1) {
+          const real *Aread = rotates ? Aoth : Acur;
+          bool nany = false;
+          for (int i = 0; i < npairs; ++i) {
+            mism += priority_misses(q0, npairs, pa[i], pb[i]); // what it reads was stored before the signal
+            PsdRot r;
+            nany |= psd_rotation_now(Aread, pa[i], pb[i], ld, k, thr, offmax, r);
+            psd_pair_advance(i, K2, pa[i], pb[i]);
+            tq[(par ^ 1) * TBL + i] = PsdPair{r.x, r.y};
+            tc[(par ^ 1) * TBL + i] = RotCS{r.c, r.s};
+          }
+          rot_any[par ^ 1] = nany;
+        }
+        if (rotates) std::swap(Acur, Aoth); // after the barrier
       }
     } else {
       bool any = false;

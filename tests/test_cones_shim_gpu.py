@@ -381,7 +381,7 @@ def test_pipelined_psd_kernel_orders_51_to_72_match_reference_cold_and_warm(cone
     ref._scs_finish_cone(wr)
     got = {}
     try:
-        for pipe in ("1", "0"):
+        for pipe in ("1", "0", "2"):   # 2 (round 6): the signal form of the pipelined step
             assert lib.scs_amd_set_option(b"psd_pipe", pipe.encode()) == 0   # read by _scs_init_cone's device workspace
             k = capi.make_cone(cone)
             c = lib._scs_init_cone(C.byref(k), m)
@@ -400,6 +400,8 @@ def test_pipelined_psd_kernel_orders_51_to_72_match_reference_cold_and_warm(cone
         lib.scs_amd_set_option(b"psd_pipe", None)
     for rep, (a, b) in enumerate(zip(got["1"], got["0"])):
         assert np.abs(a - b).max() <= 2e-12 * max(1.0, np.abs(b).max()), (cone, rep, np.abs(a - b).max())
+    for rep, (a, b) in enumerate(zip(got["2"], got["0"])):   # the signal form applies the two-phase step's own rotations
+        assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(b).max()), (cone, rep, np.abs(a - b).max())
 
 
 def test_pipelined_psd_kernel_every_order_from_2_to_72_against_numpy():

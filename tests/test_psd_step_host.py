@@ -80,3 +80,20 @@ def test_warm_started_matrix_skips_steps_identically(lib):
     _, e1, v1, c1 = _eig(lib, a, 1)
     assert c0[:3] == c1[:3] and c1[1] < c1[2] and c1[3] == 0, (c0, c1)
     assert np.abs(e0 - e1).max() <= 1e-13 * np.abs(e0).max() and np.abs(v0 - v1).max() <= 1e-12
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 6, 7, 8, 16, 31, 49, 50, 51, 64, 65, 66, 71, 72])
+def test_signal_form_is_the_two_phase_iteration_bit_for_bit(lib, k):
+    """Round 6: in the signal form of the pipelined step the update lanes own the 2 npairs PRIORITY blocks first and the rotation wave
+    reads (a_pq, a_pp, a_qq) of its next pair from the updated copy.  Pinned here: the enumeration of the blocks (priority first) still
+    covers every block exactly once (the result equals the two-phase iteration BIT FOR BIT: same rotations from the same stored values),
+    and every entry the rotation wave reads lies in a priority block of the step being applied (counter 3 == 0), for every parity of
+    the order, both blocks-per-lane instantiations and the padded odd orders."""
+    for seed, spread in ((k, 0), (200 + k, 4)):
+        a = _sym(k, seed, spread)
+        rc0, e0, v0, c0 = _eig(lib, a, 0)
+        rc2, e2, v2, c2 = _eig(lib, a, 2)
+        assert rc0 == 0 and rc2 == 0
+        assert c2[3] == 0, "the rotation wave read an entry outside the priority blocks"
+        assert c0[:3] == c2[:3], (c0, c2)
+        assert np.array_equal(e0, e2) and np.array_equal(v0, v2)
