@@ -664,6 +664,24 @@ void plan_reorder(const HostCsc &A, const ScsCone *k, bool has_P, Reorder &R) {
     R.col_new2old = std::move(c.col_new2old);
     R.row_new2old = std::move(c.row_new2old);
     R.why = "line sharing of the gathers improved by 20 % or more";
+  } else if (sizeof(real) == 8 && before > 0.8) {
+    // nothing to recover by the graph search either (e.g. a uniformly random LP: no anchors, so the one-pass screen above cannot tell):
+    // the construction of candidate 3, as for the patterns the screen does recognise
+    Candidate c3;
+    chain_home_candidate(A, k, rptr, rcol, c3);
+    measure(A, c3);
+    if (0.5 * (c3.after[0] + c3.after[1]) <= 0.85 * before) {
+      R.active = true;
+      R.after[0] = c3.after[0];
+      R.after[1] = c3.after[1];
+      R.method = c3.method;
+      R.col_new2old = std::move(c3.col_new2old);
+      R.row_new2old = std::move(c3.row_new2old);
+      R.why = "no hidden locality found by the graph search; chain + home numbering shares 15 % or more of the gathers' lines";
+    } else {
+      R.why = "no candidate numbering improved the measured line sharing";
+    }
+    R.seconds = now_s() - t0;
   } else {
     R.why = "no candidate numbering improved the measured line sharing by 20 %";
   }
