@@ -222,11 +222,11 @@ void measure(const HostCsc &A, Candidate &c) {
 //     product, and in the A' product the neighbouring columns -- rows of A', handled by the same wave back to back -- ask for the
 //     same y entry.  One entry per column turns local.
 //   * home: every row that may move (zero cone, nonnegative cone, the tail of a second-order cone: |x|_2 does not depend on the order
-//     of x -- src/cones.c:1247-1279 -- and the equilibration keeps D constant inside a cone, linsys/scs_matrix.c:257,329) goes, inside
-//     its cone's range, to the position of its FIRST column in the new order.  A unit of consecutive rows then has its first entries
-//     in a narrow window of x (A product), and a column finds the rows that call it home side by side in y (A' product).  One entry
-//     per row turns local.
-// On n = 1e6, m = 2e6, 10 per column that is 3e6 of 1e7 entries: measured 0.96 / 0.98 -> 0.73 / 0.72 distinct lines per entry.
+//     of x -- src/cones.c:1247-1279 -- and the equilibration keeps D constant inside a cone, linsys/scs_matrix.c:257,329) is keyed by
+//     ONE of its columns (picked by a hash of the row); inside its cone's range the rows are ordered by that key, cut into blocks of one
+//     line's worth of rows, and the blocks are dealt wide (blocked stride, below).  Rows with neighbouring homes share a line of x in
+//     the A product, and a column finds the rows that call it home in one line of y in the A' product.  One entry per row turns local.
+// On n = 1e6, m = 2e6, 10 per column that is 3e6 of 1e7 entries: measured 0.96 / 0.98 -> 0.77 / 0.72 distinct lines per entry.
 // Deterministic: the walks run on HOME_THREADS fixed column ranges (a walk never leaves its range), whatever the machine has.
 constexpr int HOME_THREADS = 4;
 
@@ -300,7 +300,7 @@ void chain_home_candidate(const HostCsc &A, const ScsCone *k, const std::vector<
     if (atoi(e) == 3) std::iota(c.col_new2old.begin(), c.col_new2old.end(), 0); // measurements: homes only, columns as given
   std::vector<int> colpos((size_t)n);
   for (int j = 0; j < n; ++j) colpos[c.col_new2old[j]] = j;
-  // ---- home: first column (in the new order) of every row
+  // ---- home: one column of every row
   // Which of its columns a row calls home: ONE PICKED BY A HASH OF THE ROW, not the first in the new order.  With the first column
   // (measured, profiles/r6_chain_home.md) a row's other entries all lie to the right of its home, so a unit of rows late in the
   // order gathers from a compressed range of x and falls out of step with the window of x the rest of the chip is gathering from

@@ -18,10 +18,12 @@
 // (c) round 6 -- "chain + home" for patterns WITHOUT hidden locality (what rounds 4-5 skipped): nothing can make most gathers of a
 // uniformly random matrix share lines, but a fixed share can be made local by construction -- columns numbered along greedy walks in
 // which neighbours share a row (one line of x serves both entries of that row; the neighbouring columns ask for the same y entry),
-// and every movable row placed, inside its cone's range, at the position of its first column.  Movable here also means the TAIL of a
+// and every movable row keyed by one of its columns, the rows of a cone's range ordered by that key in line-sized blocks that are
+// dealt wide (so that no unit of consecutive rows piles its entries on one spot of x).  Movable here also means the TAIL of a
 // second-order cone: |x|_2 does not depend on the order of x (src/cones.c:1247-1279), D is constant inside a cone
 // (linsys/scs_matrix.c:257,329) and R_y too (src/cones.c:349-363); the cone's first row t stays.  ~3 of 10 entries per column turn
-// local on the headline family: 0.96 / 0.98 -> 0.75 / 0.71 distinct lines per gathered entry (kept from 15 % on).
+// local on the headline family: 0.96 / 0.98 -> 0.77 / 0.72 distinct lines per gathered entry (kept from 15 % on); both CG products
+// 65 - 67 -> 56 us (profiles/r6_chain_home.md).
 // The solve then runs entirely in the new numbering; scs_update / warm starts / the returned (x, y, s) are mapped at the
 // API boundary (admm.hip), so callers never see it.  P != NULL disables it (a symmetric permutation of the upper triangle
 // is not implemented).  SCS_AMD_REORDER=0 switches it off, =1 forces the attempt on small problems too (tests).
