@@ -40,6 +40,10 @@ struct Reorder {
   double seconds = 0;
   const char *method = "none";
   const char *why = "not attempted";
+  // the renumbered matrix, when plan_reorder already built it (beside the measurement of the candidate, on its own threads):
+  // apply_reorder then only moves it into place
+  mutable HostCsc ready;
+  mutable bool have_ready = false;
 };
 
 // decides (and fills R); A is the caller's matrix (m x n CSC), k the cone
