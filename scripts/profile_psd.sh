@@ -14,13 +14,13 @@ rocprofv3 --kernel-trace --pmc $CTRS -d $OUT/sdp -o p -- python $R/scripts/bench
 rocprofv3 --kernel-trace --pmc $CTRS -d $OUT/big -o p -- python $R/scripts/bench_psd_sizes.py --cases 256x8 --iters 10 > $OUT/big.out 2> $OUT/big.err
 cd $R
 {
-  echo "# r2: instruction mix of the PSD kernels (rocprofv3 --kernel-trace --pmc $CTRS, scripts/profile_psd.sh, one MI355X)"
+  echo "# instruction mix of the PSD kernels (rocprofv3 --kernel-trace --pmc $CTRS, scripts/profile_psd.sh, one MI355X)"
   echo "## BASELINE configs[2]: 200 PSD blocks 50x50 + box(1001) -- k_psd_jacobi (one workgroup per block, A and V in LDS, warm start)"
   python3 scripts/rocpd_pmc.py $(ls $OUT/sdp/*results.db | head -1) 50 2>/dev/null | grep -E "k_psd|kernel|---"
   tail -3 $OUT/sdp.out
   echo "## 8 PSD blocks 256x256 -- psd_big.h (chip-wide Jacobi steps; MFMA in k_bp_gemm_tn (warm start) and k_bp_gram (reconstruction))"
-  python3 scripts/rocpd_pmc.py $(ls $OUT/big/*results.db | head -1) 0 2>/dev/null | grep -E "k_bp_|kernel|---" | grep -E "MFMA|SQ_INSTS_VALU |kernel|---|SQ_INSTS_LDS"
-  python3 scripts/rocpd_stats.py $(ls $OUT/big/*results.db | head -1) 0 2>/dev/null | grep -E "k_bp_|kernel \||---"
+  python3 scripts/rocpd_pmc.py $(ls $OUT/big/*results.db | head -1) 0 2>/dev/null | grep -E "k_bp_|k_bj_|kernel|---" | grep -E "MFMA|SQ_INSTS_VALU |kernel|---|SQ_INSTS_LDS"
+  python3 scripts/rocpd_stats.py $(ls $OUT/big/*results.db | head -1) 0 2>/dev/null | grep -E "k_bp_|k_bj_|kernel \||---"
 } > $OUT/psd_pmc.md
 rm -rf $OUT/sdp $OUT/big
 head -40 $OUT/psd_pmc.md | cut -c1-200
