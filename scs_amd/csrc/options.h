@@ -45,7 +45,7 @@ struct OptRow {
 
 // clang-format off
 #define SCSAMD_OPTION_TABLE(X) \
-  X("reorder",          OPT_SUPPORTED, 1, "0|1",              "scs_init's internal renumbering of variables and zero/nonnegative rows: 0 off, 1 = look for one even where the size / pattern screens would not bother (default: screens, then kept only if the measured line sharing improves by >= 20 %)") \
+  X("reorder",          OPT_SUPPORTED, 1, "0|1",              "scs_init's internal renumbering of variables, zero/nonnegative rows and second-order-cone tails (callers never see it): 0 off, 1 = attempt and keep one even where the size screen would not bother (default: from 1e6 nonzeros on, a candidate is kept only if the measured line sharing of the gathers improves by 15-20 %)") \
   X("aa",               OPT_SUPPORTED, 1, "host|dev",         "Anderson acceleration on the host or on the device (default: device when n+m+1 >= 32768)") \
   X("equil",            OPT_SUPPORTED, 0, "host|dev",         "equilibration of scs_init on the host or on the device (default: device when nnz(A) >= 1e5; bit-identical)") \
   X("graph",            OPT_SUPPORTED, 0, "0|1",              "HIP-graph replay of blocks of 8 CG iterations for small systems (default on up to 2e6 nonzeros; 0 is needed under rocprofv3)") \
