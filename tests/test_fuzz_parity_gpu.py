@@ -111,10 +111,14 @@ def _base_problem(seed):
     return rng, cone, m, n, A
 
 
+@pytest.mark.parametrize("renumber", [False, True])
 @pytest.mark.parametrize("seed", range(6))
-def test_infeasible_programs_get_the_reference_status_and_a_certificate(seed):
+def test_infeasible_programs_get_the_reference_status_and_a_certificate(seed, renumber, monkeypatch):
     """Two contradictory rows in the nonnegative cone (x0 <= -1 and x0 >= 1): primal infeasible.
-    Same status as the reference (SCS_INFEASIBLE = -2) and a valid certificate: A'y ~ 0, b'y < 0, y in K*."""
+    Same status as the reference (SCS_INFEASIBLE = -2) and a valid certificate: A'y ~ 0, b'y < 0, y in K*.
+    (renumber: the certificate comes back through the internal numbering, forced.)"""
+    if renumber:
+        monkeypatch.setenv("SCS_AMD_REORDER", "1")
     ref = pyoracle.load_ref()
     amd = capi.load("libscsamd.so")
     rng, cone, m, n, A = _base_problem(seed)
