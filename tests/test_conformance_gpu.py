@@ -17,11 +17,12 @@ pytestmark = pytest.mark.gpu
 REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
 
 
-def _run(exe, timeout):
+def _run(exe, timeout, env=None):
     path = os.path.join(REF, exe)
     if not os.path.exists(path):
         pytest.skip(f"{exe} not built (oracle/Makefile conform needs /root/reference)")
-    p = subprocess.run([path], cwd=REF, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    p = subprocess.run([path], cwd=REF, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout,
+                       env=dict(os.environ, **env) if env else None)
     return p.returncode, p.stdout
 
 
@@ -35,8 +36,11 @@ def test_reference_test_suite_passes_over_our_boundary(exe, count):
     assert m and int(m.group(1)) == count, tail
 
 
-def test_reference_problems_pass_over_our_whole_solver():
-    rc, out = _run("conform_b2", 600)
+@pytest.mark.parametrize("renumber", [False, True])
+def test_reference_problems_pass_over_our_whole_solver(renumber):
+    """renumber (round 6): the same 53 reference problems with scs_init's internal numbering FORCED on every problem that has no P
+    (option reorder = 1 through its environment fallback): the reference's own verification helpers judge x, y, s in ITS order."""
+    rc, out = _run("conform_b2", 600, env={"SCS_AMD_REORDER": "1"} if renumber else None)
     tail = out[-2000:]
     assert rc == 0, tail
     m = re.search(r"CONFORM SUMMARY: (\d+) run, (\d+) failed", out)
