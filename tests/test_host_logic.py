@@ -295,3 +295,15 @@ def test_row_sharded_pcg_over_two_gloo_ranks():
     assert d["world"] == 2 and d["rows"] == [0, 401]
     assert d["cg_iters"] > 10 and d["allreduce_calls"] >= d["cg_iters"]
     assert d["err"] <= 1e-9, d
+
+
+def test_parallel_host_transpose_of_the_b1_boundary_equals_the_serial_one(tmp_path):
+    """Round 6: scs_init_lin_sys_work's CSC -> CSR transpose (host arrays at the B1 boundary; linsys/cpu/indirect/private.c:7-46) runs on four
+    threads from a few million entries on (the nnz = 2.2e9 run spent two minutes in the serial loop).  Pinned on the CPU: byte-identical
+    to the serial counting sort for ragged / empty columns, 32- and 64-bit entry positions, fp64 and fp32 (scs_amd/csrc/host_transpose.h)."""
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = str(tmp_path / "libtr.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", so, os.path.join(here, "native", "host_check_transpose.cpp")])
+    assert ctypes.CDLL(so).transpose_check() == 0
