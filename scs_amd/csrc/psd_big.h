@@ -31,6 +31,7 @@ struct BigPsdCtl {
   real thr, fro;
   unsigned long long offmax_bits[2]; // bit pattern of the largest |a_pq| met in a sweep (non-negative: orders like the value), by sweep parity:
                                      // the fused step (k_bj_fused) runs the first inner sweep of sweep s + 1 before sweep s is closed
+  unsigned long long left_bits;   // the same of the largest off-diagonal entry of the matrix as the sweep just closed LEFT it (k_bp_offscan)
   int cur[2];                     // which A copy holds the block before launch g: cur[g & 1] (written for g+1 by the launch itself)
   int done, sweeps, kraw; // kraw: signed order (negative = complex embedding), copied here so that a step kernel
                           // needs ONE dependent read (this record) before it touches A
@@ -84,31 +85,45 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_unpack(BigPsdView B, const re
   }
 }
 
-// Frobenius norm (fixed summation order: one workgroup per block), threshold, control record armed
-__global__ __launch_bounds__(BP_PARAM_THREADS) void k_bp_norm(BigPsdView B) {
-  __shared__ real red[BP_PARAM_THREADS / SCSAMD_WAVE];
-  const int b = blockIdx.y;
+// Frobenius norm, threshold, control record armed.  Two launches with a fixed summation order (round 6): BP_NORM_G workgroups per block
+// sum whole columns (column j goes to workgroup j mod BP_NORM_G; coalesced, no index division) into one partial each, one workgroup
+// per block adds the partials in their order.  (Rounds 2-5: ONE workgroup per block walked the whole matrix with a 64-bit division per
+// entry -- 31 us at order 256, 407 us at order 1024, 4 % of that projection.)
+constexpr int BP_NORM_G = 64;
+__global__ __launch_bounds__(BP_THREADS) void k_bp_norm_part(BigPsdView B, real *__restrict__ part) {
+  __shared__ real red[BP_THREADS / SCSAMD_WAVE];
+  const int b = blockIdx.y, g = blockIdx.x;
   const BlockShape s = bp_shape(B, b);
   const real *A = B.A + (size_t)b * B.ld * B.ld;
   real fro = 0;
-  const long long total = (long long)s.K2 * s.K2;
-  for (long long e = threadIdx.x; e < total; e += BP_PARAM_THREADS) {
-    const real v = A[(size_t)(e / s.K2) * B.ld + (e % s.K2)];
-    fro += v * v;
+  for (int j = g; j < s.K2; j += BP_NORM_G) {
+    const real *col = A + (size_t)j * B.ld;
+    for (int i = threadIdx.x; i < s.K2; i += BP_THREADS) {
+      const real v = col[i];
+      fro += v * v;
+    }
   }
-  fro = sqrt(block_sum(fro, red));
-  if (threadIdx.x == 0) {
-    const real eps = sizeof(real) == 8 ? (real)1e-15 : (real)1e-7;
-    BigPsdCtl *c = B.ctl + b;
-    c->fro = fro;
-    // same rule as k_psd_jacobi (fp32: not below the rounding noise of the rotations)
-    c->thr = sizeof(real) == 8 ? eps * fro / (real)s.k : fmaxf(eps * fro / (real)s.k, (real)2.4e-7 * fro);
-    c->offmax_bits[0] = c->offmax_bits[1] = 0ull;
-    c->cur[0] = c->cur[1] = 0;
-    c->done = fro > (real)0 ? 0 : 1;
-    c->sweeps = 0;
-    c->kraw = B.psd_k[B.id[b]];
-  }
+  fro = block_sum(fro, red);
+  if (threadIdx.x == 0) part[(size_t)b * BP_NORM_G + g] = fro;
+}
+__global__ __launch_bounds__(SCSAMD_WAVE) void k_bp_norm(BigPsdView B, const real *__restrict__ part) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const BlockShape s = bp_shape(B, b);
+  real fro = 0;
+  for (int g = 0; g < BP_NORM_G; ++g) fro += part[(size_t)b * BP_NORM_G + g];
+  fro = sqrt(fro);
+  const real eps = sizeof(real) == 8 ? (real)1e-15 : (real)1e-7;
+  BigPsdCtl *c = B.ctl + b;
+  c->fro = fro;
+  // same rule as k_psd_jacobi (fp32: not below the rounding noise of the rotations)
+  c->thr = sizeof(real) == 8 ? eps * fro / (real)s.k : fmaxf(eps * fro / (real)s.k, (real)2.4e-7 * fro);
+  c->offmax_bits[0] = c->offmax_bits[1] = 0ull;
+  c->left_bits = 0ull;
+  c->cur[0] = c->cur[1] = 0;
+  c->done = fro > (real)0 ? 0 : 1;
+  c->sweeps = 0;
+  c->kraw = B.psd_k[B.id[b]];
 }
 
 __device__ __forceinline__ unsigned long long bp_bits(real v) { // v >= 0
@@ -951,9 +966,9 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real 
                  Sbuf2 + F.qout * qsz + slot_q * BJ_W * BJ_W, Qflag2 + F.qout * fsz + slot_q);
 }
 
-// closes a sweep for every block; *remaining = blocks still iterating
-__global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// closes a sweep for every block (one thread); remaining[0] = blocks still iterating.  scanned: left_bits holds the largest off-diagonal
+// entry of the matrix as this sweep left it
+__device__ __forceinline__ void bp_close_sweep(const BigPsdView &B, int *status, int *remaining, bool scanned) {
   int rem = 0, worked = 0;
   for (int b = 0; b < B.nbig; ++b) {
     BigPsdCtl *c = B.ctl + b;
@@ -961,7 +976,9 @@ __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
     worked = 1;
     const int par = c->sweeps & 1;
     c->sweeps += 1;
-    if (bp_from_bits(c->offmax_bits[par]) <= c->thr) {
+    const bool nothing_left = scanned && bp_from_bits(c->left_bits) <= c->thr; // the next sweep would rotate nothing
+    c->left_bits = 0ull;
+    if (bp_from_bits(c->offmax_bits[par]) <= c->thr || nothing_left) {
       c->done = 1;
     } else if (c->sweeps >= PSD_MAX_SWEEPS) {
       c->done = 1;
@@ -973,6 +990,37 @@ __global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining) {
   }
   remaining[0] = rem;
   remaining[1] += worked; // sweeps of this projection in which some block still iterated (the host sizes its next batch from it)
+}
+__global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining, int scanned) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  bp_close_sweep(B, status, remaining, scanned != 0);
+}
+
+// The largest off-diagonal entry of every block that is still iterating, in the matrix as the sweep just run leaves it (round 6).
+// The iteration ends with a sweep that meets no entry above the threshold, i.e. one that rotates nothing: whether the NEXT sweep
+// would be that one can be read off the matrix in one pass (8 MB at order 1024) instead of being found out by running it (32
+// launches of ~20 us there, 8 at order 256: 5 % of a cold projection, a third to a half of a warm-started one of 2 - 3 sweeps).
+// Same rule (|a_pq| > thr rotates, both indices below k), same final matrix bit for bit; both triangles are read, so whichever mirror
+// entry a rotation would have looked at is covered.  slot: parity of the next launch (ctl.cur), as k_bp_scale.
+// (Closing the sweep from the workgroup that finishes last -- a ticket behind a fence -- instead of k_bp_sweep_end's launch was
+// measured and dropped: an agent-scope fence per workgroup writes the XCD's L2 back; 100 x 32: 1.73 vs 1.35 ms per projection.)
+__global__ __launch_bounds__(BP_THREADS) void k_bp_offscan(BigPsdView B, int slot) {
+  __shared__ real red[BP_THREADS / SCSAMD_WAVE];
+  const int b = blockIdx.y;
+  BigPsdCtl *c = B.ctl + b;
+  if (c->done) return;
+  const BlockShape s = bp_shape_raw(c->kraw);
+  const real *A = (c->cur[slot] ? B.A1 : B.A) + (size_t)b * B.ld * B.ld;
+  real mx = 0;
+  for (int j = blockIdx.x; j < s.k; j += gridDim.x) {
+    const real *col = A + (size_t)j * B.ld;
+    for (int i = threadIdx.x; i < s.k; i += BP_THREADS) {
+      const real a = absval(col[i]);
+      if (i != j && a > mx) mx = a;
+    }
+  }
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0 && mx > (real)0) atomicMax(&c->left_bits, bp_bits(mx));
 }
 
 // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044), in place
@@ -1154,6 +1202,8 @@ struct BigPsd {
   int sweeps_hint[2] = {0, 0}; // sweeps the previous projection of the same kind ([0] cold start, [1] warm start) needed: that many minus one
                              // are enqueued before the first read-back (a cold projection's ~10 must not size the next warm one's batch)
   bool fused = true;         // blocked: one launch per outer step (k_bj_fused) instead of k_bj_inner + k_bj_update
+  DevBuf<real> normpart;     // k_bp_norm_part's partial sums
+  bool offscan = true;       // a pass over the matrix after every sweep decides whether another sweep would rotate anything (k_bp_offscan)
   bool cross = true;         // blocked: every index pair once per sweep (within pass + cross-pair tournament steps), see bj_pair_sched
   DevBuf<real> Qbuf, Sbuf;   // blocked: per (block, block-column pair) the 64 x 64 factor Q and rotated subproblem S'
   DevBuf<int> Qflag;         // ... and whether the pair's inner sweep rotated at all
@@ -1175,6 +1225,9 @@ struct BigPsd {
     blocked = true;
     if (const char *e = opt_get("psd_blocked")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
     ld = blocked ? (kmax + BJ_W - 1) / BJ_W * BJ_W : (kmax + 1) & ~1;
+    normpart.alloc((size_t)nbig * BP_NORM_G);
+    offscan = true;
+    if (const char *e = opt_get("psd_offscan")) offscan = atoi(e) != 0; // 0: rounds 2-5's closing sweep that rotates nothing (A/B measurements)
     cross = true;
     if (const char *e = opt_get("psd_cross")) cross = atoi(e) != 0; // 0: full 63-step sweeps of every block-column pair (first form of round 3)
     if (blocked) {
@@ -1225,7 +1278,8 @@ struct BigPsd {
       hipLaunchKernelGGL(k_bp_gemm_tn, dim3(g_mm, nbig), dim3(BP_THREADS), 0, st, B, A.p, (const real *)V.p, (const real *)Tm.p); // A = Vp' T
       hipLaunchKernelGGL(k_bp_symm, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B);
     }
-    hipLaunchKernelGGL(k_bp_norm, dim3(1, nbig), dim3(BP_PARAM_THREADS), 0, st, B);
+    hipLaunchKernelGGL(k_bp_norm_part, dim3(BP_NORM_G, nbig), dim3(BP_THREADS), 0, st, B, normpart.p);
+    hipLaunchKernelGGL(k_bp_norm, dim3(nbig), dim3(SCSAMD_WAVE), 0, st, B, (const real *)normpart.p);
     int h_rem[2] = {nbig, 0};
     long long qgen = 0;  // fused step: generations of Q / S' / flags written so far
     bool first_launch = true;
@@ -1237,7 +1291,8 @@ struct BigPsd {
     // read-back, then one at a time (consecutive ADMM iterates need nearly the same count; a block that has converged makes every
     // later launch return at once, as in the PCG loop; the sweep cap of cones.c:1031 is enforced on the device).  One host
     // round trip per sweep cost 50 - 100 us -- a third of a projection of 32 blocks of order 100.
-    int enq = 0, batch = std::max(1, std::min(sweeps_hint[warm ? 1 : 0] - 1, warm ? 8 : 12));
+    const int g_scan = std::max(1, std::min(ld / 8, 64)); // whole columns, eight or more per workgroup
+    int enq = 0, batch = std::max(1, std::min(sweeps_hint[warm ? 1 : 0] - 1, warm ? 8 : 12)); // (all of them: measured the same, 2.70 vs 2.71 ms at 256 x 8)
     while (h_rem[0] > 0 && enq < PSD_MAX_SWEEPS + 4) {
      for (int bsw = 0; bsw < batch; ++bsw, ++enq) {
       if (blocked) {
@@ -1268,7 +1323,8 @@ struct BigPsd {
         for (int step = 0; step < ld - 1; ++step, ++gstep)
           hipLaunchKernelGGL(k_bp_step, dim3(g_step, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1) | (step << 1));
       }
-      hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p);
+      if (offscan) hipLaunchKernelGGL(k_bp_offscan, dim3(g_scan, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1));
+      hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p, offscan ? 1 : 0);
      }
       HIP_CHECK(hipMemcpyAsync(h_rem, remaining.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
