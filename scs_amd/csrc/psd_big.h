@@ -966,11 +966,11 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real 
                  Sbuf2 + F.qout * qsz + slot_q * BJ_W * BJ_W, Qflag2 + F.qout * fsz + slot_q);
 }
 
-// closes a sweep for every block (one thread); remaining[0] = blocks still iterating.  scanned: left_bits holds the largest off-diagonal
-// entry of the matrix as this sweep left it
-__device__ __forceinline__ void bp_close_sweep(const BigPsdView &B, int *status, int *remaining, bool scanned) {
+// closes a sweep for every block (one wave, a lane per block); remaining[0] = blocks still iterating.  scanned: left_bits holds the largest
+// off-diagonal entry of the matrix as this sweep left it
+__global__ __launch_bounds__(SCSAMD_WAVE) void k_bp_sweep_end(BigPsdView B, int *status, int *remaining, int scanned) {
   int rem = 0, worked = 0;
-  for (int b = 0; b < B.nbig; ++b) {
+  for (int b = threadIdx.x; b < B.nbig; b += SCSAMD_WAVE) {
     BigPsdCtl *c = B.ctl + b;
     if (c->done) continue;
     worked = 1;
@@ -988,12 +988,12 @@ __device__ __forceinline__ void bp_close_sweep(const BigPsdView &B, int *status,
     }
     c->offmax_bits[par] = 0ull;
   }
-  remaining[0] = rem;
-  remaining[1] += worked; // sweeps of this projection in which some block still iterated (the host sizes its next batch from it)
-}
-__global__ void k_bp_sweep_end(BigPsdView B, int *status, int *remaining, int scanned) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  bp_close_sweep(B, status, remaining, scanned != 0);
+  rem = wave_sum(rem);
+  worked = wave_max(worked);
+  if (threadIdx.x == 0) {
+    remaining[0] = rem;
+    remaining[1] += worked; // sweeps of this projection in which some block still iterated (the host sizes its next batch from it)
+  }
 }
 
 // The largest off-diagonal entry of every block that is still iterating, in the matrix as the sweep just run leaves it (round 6).
@@ -1020,7 +1020,8 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_offscan(BigPsdView B, int slo
     }
   }
   mx = block_max(mx, red);
-  if (threadIdx.x == 0 && mx > (real)0) atomicMax(&c->left_bits, bp_bits(mx));
+  // (the plain read may be stale, i.e. too small: then the atomic is issued needlessly, never skipped wrongly)
+  if (threadIdx.x == 0 && mx > bp_from_bits(c->left_bits)) atomicMax(&c->left_bits, bp_bits(mx));
 }
 
 // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044), in place
@@ -1038,8 +1039,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_scale(BigPsdView B, int slot)
 }
 
 // X+ = W W', packed lower triangle with diagonal / sqrt(2) (cones.c:1052-1063): real blocks on the fp64 matrix cores,
-// one 16x16 output tile per wave (lane l supplies W[row l&15][k l>>4] for both operands; D element (row (l>>4) + 4 reg,
-// col l&15)).  Complex blocks and the fp32 build: one lane per packed output entry.
+// 16x16 MFMA tiles (lane l supplies W[row l&15][k l>>4] for both operands; D element (row (l>>4) + 4 reg, col l&15)).  Complex blocks and the fp32 build: one lane per packed output entry.
 __global__ __launch_bounds__(BP_THREADS) void k_bp_gram(BigPsdView B, real *x) {
   const int b = blockIdx.y;
   const BlockShape s = bp_shape(B, b);
@@ -1073,8 +1073,10 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_gram(BigPsdView B, real *x) {
     return;
   }
 #ifndef SFLOAT
+  // (round 6) a wave owns a 32 x 32 tile of the lower triangle: 2 x 2 MFMA tiles, every fragment of W feeds two products; the tile above
+  // the diagonal of a diagonal 32 x 32 tile is not formed.  Additions into every entry in the order of rounds 2-5 (same bits).
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = BP_THREADS >> 6;
-  const int T = (k + 15) >> 4;
+  const int T = (k + 31) >> 5;
   const long long ntile = (long long)T * (T + 1) / 2;
   const int ksteps = (s.K2 + 3) >> 2;
   const int li = lane & 15, lk = lane >> 4;
@@ -1084,19 +1086,49 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_gram(BigPsdView B, real *x) {
     while ((long long)ti * (ti + 1) / 2 > t) --ti;
     while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = (int)(t - (long long)ti * (ti + 1) / 2);
-    f64x4 acc = {0, 0, 0, 0};
-    const int ra = ti * 16 + li, rb = tj * 16 + li;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int kc = ks * 4 + lk;
-      const double av = (ra < k && kc < s.K2) ? W[kc * ld + ra] : 0.0;
-      const double bv = (rb < k && kc < s.K2) ? W[kc * ld + rb] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    const bool diag_tile = ti == tj;
+    f64x4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    const int ra = ti * 32 + li, rb = tj * 32 + li;
+    // eight steps (32 summation indices, 28 - 32 products) per trip, the next trip's fragments asked for before this one's products
+    // (one step ahead was measured: 179 us at order 1024 against 118 for round 5's 16 x 16 tiles -- the L2 latency showed whole)
+    constexpr int GS = 8;
+    auto frag = [&](int ks0, double (&av)[GS][2], double (&bv)[GS][2]) {
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        const int kc = (ks0 + u) * 4 + lk;
+        const bool kin = kc < s.K2; // (beyond the last step: zeros, not used)
+        const real *col = W + (size_t)kc * ld;
+        av[u][0] = (kin && ra < k) ? col[ra] : 0.0;
+        av[u][1] = (kin && ra + 16 < k) ? col[ra + 16] : 0.0;
+        bv[u][0] = (kin && rb < k) ? col[rb] : 0.0;
+        bv[u][1] = (kin && rb + 16 < k) ? col[rb + 16] : 0.0;
+      }
+    };
+    double av[GS][2], bv[GS][2], an[GS][2], bn[GS][2];
+    frag(0, av, bv);
+    for (int ks = 0; ks < ksteps; ks += GS) {
+      frag(ks + GS, an, bn);
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        if (ks + u < ksteps) { // (uniform)
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[u][0], acc[0][0], 0, 0, 0);
+          if (!diag_tile) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[u][1], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[u][0], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[u][1], acc[1][1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GS; ++u) av[u][0] = an[u][0], av[u][1] = an[u][1], bv[u][0] = bn[u][0], bv[u][1] = bn[u][1];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
-      if (i < k && j <= i) X[packed_index(i, j, k)] = i == j ? acc[r] * inv_sqrt2 : acc[r];
-    }
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ti * 32 + x * 16 + lk + 4 * r, j = tj * 32 + y * 16 + li;
+          if (i < k && j <= i) X[packed_index(i, j, k)] = i == j ? acc[x][y][r] * inv_sqrt2 : acc[x][y][r];
+        }
   }
 #else
   const long long ntri = (long long)k * (k + 1) / 2;
@@ -1123,10 +1155,24 @@ __global__ void k_bp_set_kraw(BigPsdView B, int *remaining) {
 }
 
 // C = L' R for K2 x K2 column-major matrices (both operands contiguous along the summation index): the two products
-// of the warm start A' = Vp' (A Vp) -- A is symmetric, so A Vp = A' Vp.  fp64 matrix cores, one 16x16 tile of C per wave;
-// lane (li = l & 15, lk = l >> 4) owns the summation indices 16 kk + 4 lk + s for MFMA step s of chunk kk (any
-// assignment works as long as both operands use the same one), i.e. one 32-byte run per operand and chunk, so a wave
-// reads whole 128-byte lines.  fp32 build: plain loops.
+// of the warm start A' = Vp' (A Vp) -- A is symmetric, so A Vp = A' Vp.  fp64 matrix cores; lane (li = l & 15, lk = l >> 4) owns
+// the summation indices 16 kk + 4 lk + s for MFMA step s of chunk kk (any assignment works as long as both operands use the same
+// one), i.e. one 32-byte run per operand and chunk, so a wave reads whole 128-byte lines.
+// Round 6: a wave owns a 32 x 32 tile of C (2 x 2 MFMA tiles: every operand fragment feeds two products, half the L2 traffic per
+// flop) and asks for chunk kk + 1 before it multiplies chunk kk.  Rounds 2-5: one 16 x 16 tile per wave, loads and products in turn --
+// 234 us per product at order 1024 (9 TFLOP/s).  The order of the additions into every entry of C is unchanged (same bits).
+// fp32 build: plain loops.
+__device__ __forceinline__ void bp_frag4(const real *__restrict__ M, size_t ld, int row, int k0, int K2, double (&f)[4]) {
+#ifndef SFLOAT
+  if (row < K2 && k0 + 3 < K2) { // (k0 is a multiple of 4 and ld is even: 16-byte aligned)
+    const double2 lo = *reinterpret_cast<const double2 *>(M + (size_t)row * ld + k0), hi = *reinterpret_cast<const double2 *>(M + (size_t)row * ld + k0 + 2);
+    f[0] = lo.x, f[1] = lo.y, f[2] = hi.x, f[3] = hi.y;
+    return;
+  }
+#endif
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f[q] = (row < K2 && k0 + q < K2) ? (double)M[(size_t)row * ld + k0 + q] : 0.0;
+}
 __global__ __launch_bounds__(BP_THREADS) void k_bp_gemm_tn(BigPsdView B, real *C, const real *__restrict__ L, const real *__restrict__ R) {
   const int b = blockIdx.y;
   const BlockShape s = bp_shape_raw(B.ctl[b].kraw);
@@ -1137,29 +1183,56 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_gemm_tn(BigPsdView B, real *C
   R += mat;
 #ifndef SFLOAT
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = BP_THREADS >> 6;
-  const int T = (K2 + 15) >> 4, li = lane & 15, lk = lane >> 4;
+  const int T = (K2 + 31) >> 5, li = lane & 15, lk = lane >> 4;
   const int chunks = (K2 + 15) >> 4;
   for (long long t = (long long)blockIdx.x * nw + wave; t < (long long)T * T; t += (long long)gridDim.x * nw) {
     const int ti = (int)(t % T), tj = (int)(t / T);
-    const int ra = ti * 16 + li, cb = tj * 16 + li;
-    f64x4 acc = {0, 0, 0, 0};
-    for (int kk = 0; kk < chunks; ++kk) {
-      const int k0 = kk * 16 + lk * 4;
-      double a[4], bb[4];
+    const int ra = ti * 32 + li, cb = tj * 32 + li;
+    f64x4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    // two chunks (32 summation indices, 32 products = ~2000 clocks of the matrix core) per trip, the next trip's fragments asked for
+    // before the products of this one: with one wave per SIMD (order 1024: 1024 tiles) nothing else hides the L2 latency
+    double a[2][2][4], bb[2][2][4], an[2][2][4], bn[2][2][4]; // [chunk of the trip][tile row / column][step]
+    auto trip = [&](int kk, double (&fa)[2][2][4], double (&fb)[2][2][4]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ok = k0 + q < K2;
-        a[q] = (ok && ra < K2) ? L[ra * ld + k0 + q] : 0.0;
-        bb[q] = (ok && cb < K2) ? R[cb * ld + k0 + q] : 0.0;
+      for (int c = 0; c < 2; ++c) {
+        const int k0 = (kk + c) * 16 + lk * 4; // (beyond the last chunk: zeros, not used)
+        bp_frag4(L, ld, ra, k0, K2, fa[c][0]);
+        bp_frag4(L, ld, ra + 16, k0, K2, fa[c][1]);
+        bp_frag4(R, ld, cb, k0, K2, fb[c][0]);
+        bp_frag4(R, ld, cb + 16, k0, K2, fb[c][1]);
+      }
+    };
+    trip(0, a, bb);
+    for (int kk = 0; kk < chunks; kk += 2) {
+      trip(kk + 2, an, bn);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (kk + c < chunks) { // (uniform)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+              for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][x][q], bb[c][y][q], acc[x][y], 0, 0, 0);
+          }
+        }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bb[q], acc, 0, 0, 0);
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[c][x][q] = an[c][x][q], bb[c][x][q] = bn[c][x][q];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ti * 16 + lk + 4 * r, j = tj * 16 + li;
-      if (i < K2 && j < K2) C[j * ld + i] = acc[r];
-    }
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ti * 32 + x * 16 + lk + 4 * r, j = tj * 32 + y * 16 + li;
+          if (i < K2 && j < K2) C[(size_t)j * ld + i] = acc[x][y][r];
+        }
   }
 #else
   for (long long e = (long long)blockIdx.x * BP_THREADS + threadIdx.x; e < (long long)K2 * K2; e += (long long)gridDim.x * BP_THREADS) {
@@ -1271,8 +1344,8 @@ struct BigPsd {
     hipLaunchKernelGGL(k_bp_set_kraw, dim3((nbig + 63) / 64), dim3(64), 0, st, B, remaining.p);
     hipLaunchKernelGGL(k_bp_unpack, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B, x, warm ? 0 : 1, blocked ? 1 : 0);
     if (warm) {
-      const long long T16 = (ld + 15) / 16;
-      const int g_mm = (int)std::min<long long>((T16 * T16 + 3) / 4, 8192);
+      const long long T32 = (ld + 31) / 32;
+      const int g_mm = (int)std::min<long long>((T32 * T32 + 3) / 4, 8192); // one 32 x 32 tile per wave
       HIP_CHECK(hipMemcpyAsync(V.p, Vp.p, mat_bytes, hipMemcpyDeviceToDevice, st));
       hipLaunchKernelGGL(k_bp_gemm_tn, dim3(g_mm, nbig), dim3(BP_THREADS), 0, st, B, Tm.p, (const real *)A.p, (const real *)V.p); // T = A' Vp = A Vp
       hipLaunchKernelGGL(k_bp_gemm_tn, dim3(g_mm, nbig), dim3(BP_THREADS), 0, st, B, A.p, (const real *)V.p, (const real *)Tm.p); // A = Vp' T
@@ -1291,7 +1364,7 @@ struct BigPsd {
     // read-back, then one at a time (consecutive ADMM iterates need nearly the same count; a block that has converged makes every
     // later launch return at once, as in the PCG loop; the sweep cap of cones.c:1031 is enforced on the device).  One host
     // round trip per sweep cost 50 - 100 us -- a third of a projection of 32 blocks of order 100.
-    const int g_scan = std::max(1, std::min(ld / 8, 64)); // whole columns, eight or more per workgroup
+    const int g_scan = std::max(1, std::min(ld / 2, std::max(ld / 8, 1024 / nbig))); // whole columns per workgroup; ~1024 workgroups in all (order 1024 on 64: 21 us)
     int enq = 0, batch = std::max(1, std::min(sweeps_hint[warm ? 1 : 0] - 1, warm ? 8 : 12)); // (all of them: measured the same, 2.70 vs 2.71 ms at 256 x 8)
     while (h_rem[0] > 0 && enq < PSD_MAX_SWEEPS + 4) {
      for (int bsw = 0; bsw < batch; ++bsw, ++enq) {
@@ -1324,7 +1397,7 @@ struct BigPsd {
           hipLaunchKernelGGL(k_bp_step, dim3(g_step, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1) | (step << 1));
       }
       if (offscan) hipLaunchKernelGGL(k_bp_offscan, dim3(g_scan, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1));
-      hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(1), 0, st, B, status, remaining.p, offscan ? 1 : 0);
+      hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(SCSAMD_WAVE), 0, st, B, status, remaining.p, offscan ? 1 : 0);
      }
       HIP_CHECK(hipMemcpyAsync(h_rem, remaining.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
@@ -1340,7 +1413,7 @@ struct BigPsd {
       have_basis = true;
     }
     hipLaunchKernelGGL(k_bp_scale, dim3(g_elem, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1));
-    const long long T = (kmax + 15) / 16, ntile = T * (T + 1) / 2;
+    const long long T = (kmax + 31) / 32, ntile = T * (T + 1) / 2; // 32 x 32 tiles of the lower triangle, one per wave
     const long long outs = (long long)kmax * (kmax + 1) / 2;
     const int g_gram = (int)std::min<long long>(std::max<long long>((ntile + 3) / 4, (outs + 64LL * BP_THREADS - 1) / (64LL * BP_THREADS)), 8192);
     hipLaunchKernelGGL(k_bp_gram, dim3(std::max(1, g_gram), nbig), dim3(BP_THREADS), 0, st, B, x);
