@@ -726,7 +726,7 @@ def secondary_single_gpu(args, headline_prob=None):
         out["psd_large_blocks"] = dict(
             workload="random SDPs with B PSD blocks of order k (92x64 = the largest order of the LDS kernel; 256x8 and 1024x1 = the blocked "
                      "iteration of scs_amd/csrc/psd_big.h), 40 ADMM iterations each, cold start, HIP events around the cone kernels",
-            cases=rows, targets_ms="VERDICT r3: 92x64 <= 2, 256x8 <= 2.5, 1024x1 <= 10", evidence="profiles/r4_psd_fused_step.md")
+            cases=rows, targets_ms="VERDICT r3: 92x64 <= 2, 256x8 <= 2.5, 1024x1 <= 10", evidence="profiles/r6_psd_big.md, profiles/r4_psd_fused_step.md")
     except Exception as e:
         out["psd_large_blocks"] = dict(error=str(e))
     # ---- the headline problem under the reference's DEFAULT settings: acceleration_lookback = 10 (include/glbopts.h:45),
