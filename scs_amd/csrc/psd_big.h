@@ -857,11 +857,28 @@ struct BjFusedArgs {
   int next_sweep;  // inner sweep belongs to the sweep after the current one (inn_step == 0 of it)
   int qin, qout;   // which of the two Q / S' / flag buffers the update reads / the inner sweep writes
   int cross;
+  int one_d;       // one-dimensional grid, inner-sweep workgroups of all blocks first (0: x = job, y = block; A/B measurements)
 };
 
 __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real *Qbuf2, real *Sbuf2, int *Qflag2, int npmax, BjFusedArgs F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bj_smem[];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  // One-dimensional grid (round 6): the inner-sweep workgroups of ALL blocks first, then the update workgroups.  Workgroups are handed
+  // out in the order of their index and one fits a CU (135 KB of LDS); with (x = job, y = block) the inner sweeps of the later blocks
+  // -- the launch's critical path, ~40 us -- queued behind the ~11 us update jobs of the earlier ones whenever a launch has more
+  // workgroups than the chip has CUs (16 blocks of order 200: 480; 4 of 512: 432).  bx: the job index of the old x dimension.
+  const int n_inner = B.nbig * npmax, tid = threadIdx.x;
+  int b, bx;
+  if (!F.one_d) {
+    b = blockIdx.y;
+    bx = blockIdx.x;
+  } else if ((int)blockIdx.x < n_inner) {
+    b = (int)blockIdx.x / npmax;
+    bx = (int)blockIdx.x - b * npmax;
+  } else {
+    const int u = (int)blockIdx.x - n_inner, per = ((int)gridDim.x - n_inner) / B.nbig;
+    b = u / per;
+    bx = npmax + (u - b * per);
+  }
   BigPsdCtl *ctl = B.ctl + b;
   const int done = ctl->done, kraw = ctl->kraw, cur = ctl->cur[F.slot];
   const BlockShape sh = bp_shape_raw(kraw);
@@ -872,15 +889,15 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real 
   const size_t qsz = (size_t)B.nbig * npmax * BJ_W * BJ_W, fsz = (size_t)B.nbig * npmax;
   const real *Qin = Qbuf2 + F.qin * qsz, *Sin = Sbuf2 + F.qin * qsz;
   const int *Fin = Qflag2 + F.qin * fsz;
-  if ((int)blockIdx.x >= npmax) { // ---- update of step upd_step
+  if (bx >= npmax) { // ---- update of step upd_step
     if (!F.do_update) return;
-    if ((int)blockIdx.x == npmax && tid == 0) ctl->cur[F.slot ^ 1] = upd_active ? cur ^ 1 : cur;
+    if (bx == npmax && tid == 0) ctl->cur[F.slot ^ 1] = upd_active ? cur ^ 1 : cur;
     if (!upd_active) return;
-    bj_update_job(B, bj_smem, Qin, Sin, Fin, npmax, b, (int)blockIdx.x - npmax, F.upd_step, F.cross, sh, Aold, (cur ? B.A : B.A1) + mat, B.V + mat);
+    bj_update_job(B, bj_smem, Qin, Sin, Fin, npmax, b, bx - npmax, F.upd_step, F.cross, sh, Aold, (cur ? B.A : B.A1) + mat, B.V + mat);
     return;
   }
   // ---- inner sweep of step inn_step on the matrix as the update of this launch leaves it
-  const int pi = blockIdx.x;
+  const int pi = bx;
   if (done || pi >= sh.nbc / 2 || (!F.next_sweep && F.inn_step >= ost)) return;
   const real thr = ctl->thr;
   const int2 IJ = bj_pair_sched(pi, F.inn_step, sh.nbc, F.cross);
@@ -1276,6 +1293,7 @@ struct BigPsd {
                              // are enqueued before the first read-back (a cold projection's ~10 must not size the next warm one's batch)
   bool fused = true;         // blocked: one launch per outer step (k_bj_fused) instead of k_bj_inner + k_bj_update
   DevBuf<real> normpart;     // k_bp_norm_part's partial sums
+  bool grid_1d = true;       // k_bj_fused: one-dimensional grid, inner-sweep workgroups of all blocks first
   bool offscan = true;       // a pass over the matrix after every sweep decides whether another sweep would rotate anything (k_bp_offscan)
   bool cross = true;         // blocked: every index pair once per sweep (within pass + cross-pair tournament steps), see bj_pair_sched
   DevBuf<real> Qbuf, Sbuf;   // blocked: per (block, block-column pair) the 64 x 64 factor Q and rotated subproblem S'
@@ -1299,6 +1317,8 @@ struct BigPsd {
     if (const char *e = opt_get("psd_blocked")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
     ld = blocked ? (kmax + BJ_W - 1) / BJ_W * BJ_W : (kmax + 1) & ~1;
     normpart.alloc((size_t)nbig * BP_NORM_G);
+    grid_1d = true;
+    if (const char *e = opt_get("psd_grid")) grid_1d = atoi(e) != 0; // 0: (job, block) grid of rounds 4-5 (A/B measurements)
     offscan = true;
     if (const char *e = opt_get("psd_offscan")) offscan = atoi(e) != 0; // 0: rounds 2-5's closing sweep that rotates nothing (A/B measurements)
     cross = true;
@@ -1374,14 +1394,14 @@ struct BigPsd {
           const int g_fused = npmax + g_upd;
           for (int step = 0; step < osteps; ++step, ++gstep) {
             if (first_launch) { // inner sweep of step 0 of the first sweep; nothing to update yet
-              const BjFusedArgs F0{(int)(gstep & 1), 0, 0, 0, 0, 0, (int)(qgen & 1), cross ? 1 : 0};
-              hipLaunchKernelGGL(k_bj_fused, dim3(npmax, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F0);
+              const BjFusedArgs F0{(int)(gstep & 1), 0, 0, 0, 0, 0, (int)(qgen & 1), cross ? 1 : 0, grid_1d ? 1 : 0};
+              hipLaunchKernelGGL(k_bj_fused, grid_1d ? dim3(npmax * nbig) : dim3(npmax, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F0);
               ++qgen;
               first_launch = false;
             }
             const bool last = step + 1 == osteps;
-            const BjFusedArgs F{(int)(gstep & 1), 1, step, last ? 0 : step + 1, last ? 1 : 0, (int)((qgen - 1) & 1), (int)(qgen & 1), cross ? 1 : 0};
-            hipLaunchKernelGGL(k_bj_fused, dim3(g_fused, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F);
+            const BjFusedArgs F{(int)(gstep & 1), 1, step, last ? 0 : step + 1, last ? 1 : 0, (int)((qgen - 1) & 1), (int)(qgen & 1), cross ? 1 : 0, grid_1d ? 1 : 0};
+            hipLaunchKernelGGL(k_bj_fused, grid_1d ? dim3(g_fused * nbig) : dim3(g_fused, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F);
             ++qgen;
           }
         } else
