@@ -857,6 +857,7 @@ struct BjFusedArgs {
   int next_sweep;  // inner sweep belongs to the sweep after the current one (inn_step == 0 of it)
   int qin, qout;   // which of the two Q / S' / flag buffers the update reads / the inner sweep writes
   int cross;
+  int flat;        // inner sweep's prologue with ONE level of global loads (0: rounds 4-5's three levels; A/B measurements)
   int one_d;       // one-dimensional grid, inner-sweep workgroups of all blocks first (0: x = job, y = block; A/B measurements)
 };
 
@@ -922,6 +923,73 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real 
     const int *flags = Fin + (size_t)b * npmax;
     const real *Qb = Qin + (size_t)b * npmax * BJ_W * BJ_W, *Sb = Sin + (size_t)b * npmax * BJ_W * BJ_W;
     const int2 prI = bj_pair_sched(PI, F.upd_step, sh.nbc, F.cross), prJ = bj_pair_sched(PJ, F.upd_step, sh.nbc, F.cross);
+    if (F.flat) {
+      // Round 6: ONE level of global loads.  Everything the subproblem is made of is asked for at once -- both candidates of every entry
+      // (S' / Q of the pairs of step k, valid memory whether or not they rotated, and A itself) beside the two flags that pick between
+      // them -- and selected when it is all here.  (Round 4's form below: flags, then the diagonal quadrants, then the tile and the Q
+      // columns, each level waiting for the one before -- three far round trips on the critical path of every launch.)
+      static_assert(BJ_UPD_THREADS == BJ_B * BJ_B, "flat prologue: one entry per quadrant and lane");
+      const int x = tid & (BJ_B - 1), y = tid >> 5;
+      const int fI = flags[PI], fJ = flags[PJ];
+      const size_t tile = (size_t)BJ_W * BJ_W;
+      auto sprime = [&](int P, int rr, int cc) -> real { return Sb[(size_t)P * tile + cc * BJ_W + rr]; };
+      auto aentry = [&](int2 pr, int rr, int cc) -> real { return Aold[(size_t)bj_gidx(pr, cc) * ld + bj_gidx(pr, rr)]; };
+      const real dIs = sprime(PI, hI * BJ_B + x, hI * BJ_B + y), dIa = aentry(prI, hI * BJ_B + x, hI * BJ_B + y);
+      const real dJs = sprime(PJ, hJ * BJ_B + x, hJ * BJ_B + y), dJa = aentry(prJ, hJ * BJ_B + x, hJ * BJ_B + y);
+      const bool swap = PI > PJ;
+      const int Pa = swap ? PJ : PI, Pb = swap ? PI : PJ, ha = swap ? hJ : hI, hb = swap ? hI : hJ;
+      const int2 pra = swap ? prJ : prI, prb = swap ? prI : prJ;
+      real cs_ = 0, ca_ = 0, xv[4] = {0, 0, 0, 0}, qv[2] = {0, 0}, pv[2] = {0, 0};
+      if (PI == PJ) { // (uniform) I' and J' sat in ONE pair of step k: the quadrant is a piece of that pair's diagonal tile too
+        cs_ = sprime(PI, hI * BJ_B + x, hJ * BJ_B + y);
+        ca_ = aentry(prI, hI * BJ_B + x, hJ * BJ_B + y);
+      } else {
+        ca_ = Aold[(size_t)bj_gidx(IJ, BJ_B + y) * ld + bj_gidx(IJ, x)]; // neither pair rotated: the update copies the tile
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int e = tid + t * BJ_UPD_THREADS, i = e & (BJ_W - 1), kk = e >> 6;
+          xv[t] = Aold[(size_t)bj_gidx(prb, kk) * ld + bj_gidx(pra, i)];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int e = tid + t * BJ_UPD_THREADS, i = e & (BJ_W - 1), j = e >> 6;
+          qv[t] = Qb[(size_t)Pb * tile + (hb * BJ_B + j) * BJ_W + i];
+          pv[t] = Qb[(size_t)Pa * tile + (ha * BJ_B + j) * BJ_W + i];
+        }
+      }
+      S[x * BJ_ILD + y] = fI ? dIs : dIa;
+      S[(BJ_B + x) * BJ_ILD + BJ_B + y] = fJ ? dJs : dJa;
+      if (PI == PJ || (!fI && !fJ)) {
+        const real v = PI == PJ ? (fI ? cs_ : ca_) : ca_;
+        S[x * BJ_ILD + BJ_B + y] = v;
+        S[(BJ_B + y) * BJ_ILD + x] = v;
+      } else {
+        // the tile (Pa <= Pb) as bj_update_job forms it: O = Q_Pa' A[Pa, Pb] Q_Pb, of which the rows of half ha and the columns of half hb
+        const int fa = swap ? fJ : fI, fb = swap ? fI : fJ;
+        real *xs = S + BJ_W * BJ_ILD; // scratch behind S (see below)
+        real *qq = xs + BJ_W * BJ_LD, *qp = qq + BJ_B * BJ_LD, *ts = qp + BJ_B * BJ_LD, *out = ts + BJ_B * BJ_LD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int e = tid + t * BJ_UPD_THREADS, i = e & (BJ_W - 1), kk = e >> 6;
+          xs[i * BJ_LD + kk] = xv[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int e = tid + t * BJ_UPD_THREADS, i = e & (BJ_W - 1), j = e >> 6;
+          qq[j * BJ_LD + i] = fb ? qv[t] : (i == hb * BJ_B + j ? (real)1 : (real)0);
+          qp[j * BJ_LD + i] = fa ? pv[t] : (i == ha * BJ_B + j ? (real)1 : (real)0);
+        }
+        __syncthreads();
+        bj_gemm_part(xs, qq, ts, 4, 2, tid, nthr);  // T[:, hb half] = X Q_Pb[:, hb half]
+        __syncthreads();
+        bj_gemm_part(qp, ts, out, 2, 2, tid, nthr); // O[ha half, hb half] = Q_Pa[:, ha half]' T
+        __syncthreads();
+        const real v = out[y * BJ_LD + x]; // O[i = x][j = y]: row x of half ha, column y of half hb
+        const int xx = swap ? y : x, yy = swap ? x : y; // xx: index in I', yy: index in J'
+        S[xx * BJ_ILD + BJ_B + yy] = v;
+        S[(BJ_B + yy) * BJ_ILD + xx] = v;
+      }
+    } else {
     const int fI = flags[PI], fJ = flags[PJ];
     // entry (hr * 32 + x, hc * 32 + y) of the diagonal tile of step-k pair P after the update: S' of the pair, or A itself if it did not rotate
     auto diag = [&](int P, int2 pr, int f, int rr, int cc) -> real {
@@ -975,6 +1043,7 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real 
         S[x * BJ_ILD + BJ_B + y] = v;
         S[(BJ_B + y) * BJ_ILD + x] = v;
       }
+    }
     }
   }
   __syncthreads();
@@ -1293,6 +1362,7 @@ struct BigPsd {
                              // are enqueued before the first read-back (a cold projection's ~10 must not size the next warm one's batch)
   bool fused = true;         // blocked: one launch per outer step (k_bj_fused) instead of k_bj_inner + k_bj_update
   DevBuf<real> normpart;     // k_bp_norm_part's partial sums
+  bool flat_prologue = true; // k_bj_fused: the inner sweep's subproblem from one level of global loads
   bool grid_1d = true;       // k_bj_fused: one-dimensional grid, inner-sweep workgroups of all blocks first
   bool offscan = true;       // a pass over the matrix after every sweep decides whether another sweep would rotate anything (k_bp_offscan)
   bool cross = true;         // blocked: every index pair once per sweep (within pass + cross-pair tournament steps), see bj_pair_sched
@@ -1317,6 +1387,8 @@ struct BigPsd {
     if (const char *e = opt_get("psd_blocked")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
     ld = blocked ? (kmax + BJ_W - 1) / BJ_W * BJ_W : (kmax + 1) & ~1;
     normpart.alloc((size_t)nbig * BP_NORM_G);
+    flat_prologue = true;
+    if (const char *e = opt_get("psd_prologue")) flat_prologue = atoi(e) != 0; // 0: rounds 4-5's three dependent levels of loads (A/B measurements)
     grid_1d = true;
     if (const char *e = opt_get("psd_grid")) grid_1d = atoi(e) != 0; // 0: (job, block) grid of rounds 4-5 (A/B measurements)
     offscan = true;
@@ -1394,13 +1466,13 @@ struct BigPsd {
           const int g_fused = npmax + g_upd;
           for (int step = 0; step < osteps; ++step, ++gstep) {
             if (first_launch) { // inner sweep of step 0 of the first sweep; nothing to update yet
-              const BjFusedArgs F0{(int)(gstep & 1), 0, 0, 0, 0, 0, (int)(qgen & 1), cross ? 1 : 0, grid_1d ? 1 : 0};
+              const BjFusedArgs F0{(int)(gstep & 1), 0, 0, 0, 0, 0, (int)(qgen & 1), cross ? 1 : 0, flat_prologue ? 1 : 0, grid_1d ? 1 : 0};
               hipLaunchKernelGGL(k_bj_fused, grid_1d ? dim3(npmax * nbig) : dim3(npmax, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F0);
               ++qgen;
               first_launch = false;
             }
             const bool last = step + 1 == osteps;
-            const BjFusedArgs F{(int)(gstep & 1), 1, step, last ? 0 : step + 1, last ? 1 : 0, (int)((qgen - 1) & 1), (int)(qgen & 1), cross ? 1 : 0, grid_1d ? 1 : 0};
+            const BjFusedArgs F{(int)(gstep & 1), 1, step, last ? 0 : step + 1, last ? 1 : 0, (int)((qgen - 1) & 1), (int)(qgen & 1), cross ? 1 : 0, flat_prologue ? 1 : 0, grid_1d ? 1 : 0};
             hipLaunchKernelGGL(k_bj_fused, grid_1d ? dim3(g_fused * nbig) : dim3(g_fused, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F);
             ++qgen;
           }

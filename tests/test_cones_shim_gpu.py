@@ -332,11 +332,13 @@ def test_measurement_forms_of_the_large_block_iteration_still_project(env, monke
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), (env, np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("env", [dict(SCS_AMD_PSD_OFFSCAN="0"), dict(SCS_AMD_PSD_GRID="0"), dict(SCS_AMD_PSD_OFFSCAN="0", SCS_AMD_PSD_GRID="0")])
+@pytest.mark.parametrize("env", [dict(SCS_AMD_PSD_OFFSCAN="0"), dict(SCS_AMD_PSD_GRID="0"), dict(SCS_AMD_PSD_PROLOGUE="0"),
+                                 dict(SCS_AMD_PSD_OFFSCAN="0", SCS_AMD_PSD_GRID="0", SCS_AMD_PSD_PROLOGUE="0")])
 def test_round_6_forms_of_the_large_block_iteration_change_no_bit(env, monkeypatch):
     """Round 6 (profiles/r6_psd_big.md): the pass over the matrix that replaces the closing sweep (a sweep that rotates nothing changes
-    nothing) and the one-dimensional grid of the fused step (same jobs, another hand-out order) are schedules, not arithmetic: against
-    rounds 4-5's forms (options psd_offscan = 0, psd_grid = 0) every projection -- cold and warm started, real and Hermitian blocks of
+    nothing), the one-dimensional grid of the fused step (same jobs, another hand-out order) and the one-level prologue of its inner
+    sweep (same entries, asked for at once) are schedules, not arithmetic: against rounds 4-5's forms (options psd_offscan = 0,
+    psd_grid = 0, psd_prologue = 0) every projection -- cold and warm started, real and Hermitian blocks of
     several sizes in one cone -- must come out bit for bit the same."""
     lib = _lib()
     cone = dict(s=[100, 150, 97], cs=[60])
