@@ -68,7 +68,7 @@ struct OptRow {
   X("psd_blocked",      OPT_AB,        1, "0|1",              "blocked tournament Jacobi for PSD orders > 92 (0 = round 2's single-column steps)") \
   X("psd_cross",        OPT_AB,        1, "0|1",              "cross sweeps of the blocked Jacobi subproblem (0 = full 63-step sweeps)") \
   X("psd_fused",        OPT_AB,        0, "0|1",              "one fused launch per outer step of the blocked Jacobi iteration (0 = two launches)") \
-  X("psd_offscan",      OPT_AB,        0, "0|1",              "PSD orders > 92: one pass over the matrix after every sweep decides whether another sweep would rotate anything (0 = find out by running it, rounds 2-5)") \
+  X("psd_offscan",      OPT_AB,        0, "0|1|2",            "PSD orders > 92: whether another sweep would rotate anything is read off the matrix as the sweep leaves it: 1 (default) = by the sweep's last update itself, 2 = by a pass of its own (k_bp_offscan), 0 = found out by running the sweep (rounds 2-5)") \
   X("psd_grid",         OPT_AB,        0, "0|1",              "PSD orders > 92, fused step: 1 (default) = one-dimensional grid with the inner-sweep workgroups of all blocks first, 0 = (job, block) grid of rounds 4-5") \
   X("psd_prologue",     OPT_AB,        0, "0|1",              "PSD orders > 92, fused step: 1 (default) = the inner sweep's subproblem from ONE level of global loads (both candidates of every entry beside the flags that pick), 0 = rounds 4-5's three dependent levels") \
   X("psd_warm_kmax",    OPT_AB,        1, "k",                "largest LDS PSD order that is warm started (72 = round 3's gate)") \

@@ -733,11 +733,15 @@ __device__ __forceinline__ void bj_gemm_part(const real *L, const real *R, real 
 __device__ __forceinline__ void bj_gemm64(const real *L, const real *R, real *O, int tid) { bj_gemm_part(L, R, O, 4, 4, tid, BJ_UPD_THREADS); }
 
 // one tile of the step `step` of block b: tile < nta -> A tile (P <= Q) and its mirror, else a V tile.  smem: 4 x 64 x BJ_LD reals.
+// left_bits (round 6; the LAST step of the block's sweep only, else null): the largest off-diagonal entry this job writes goes there --
+// the sweep's closing reads off it whether another sweep would rotate anything (see k_bp_offscan, which does the same as a pass of its
+// own for the forms that do not come through here), at the price of one atomic per workgroup instead of a launch per sweep.
 __device__ __forceinline__ void bj_update_job(const BigPsdView &B, unsigned char *smem, const real *__restrict__ Qbuf, const real *__restrict__ Sbuf,
                                               const int *__restrict__ Qflag, int npmax, int b, int tile, int step, int cross, const BlockShape &sh,
-                                              const real *Aold, real *Anew, real *V) {
+                                              const real *Aold, real *Anew, real *V, unsigned long long *left_bits = nullptr) {
   real *xs = reinterpret_cast<real *>(smem);
   real *qp = xs + BJ_W * BJ_LD, *qq = qp + BJ_W * BJ_LD, *ts = qq + BJ_W * BJ_LD;
+  __shared__ real red_left[BJ_UPD_THREADS_MAX / SCSAMD_WAVE];
   const int tid = threadIdx.x;
   const size_t ld = B.ld;
   // Only the tiles (P, Q) with P <= Q are computed; the mirror tile (Q, P) receives the transpose, so A stays EXACTLY symmetric
@@ -755,48 +759,64 @@ __device__ __forceinline__ void bj_update_job(const BigPsdView &B, unsigned char
     const int Pp = tile - Qp * (Qp + 1) / 2;
     const int2 IJp = bj_pair_sched(Pp, step, sh.nbc, cross), IJq = bj_pair_sched(Qp, step, sh.nbc, cross);
     const int fP = flags[Pp], fQ = flags[Qp];
+    real left = 0; // largest |entry| written at (row, column) with row != column, both below k (the mirror entry is the same number)
+    auto seen = [&](int gi, int gj, real v) {
+      const real a = absval(v);
+      if (gi != gj && gi < sh.k && gj < sh.k && a > left) left = a;
+    };
     if (Pp == Qp) {
       if (fP) { // the pair's own tile: the inner sweep's S' (exact zeros, relatively accurate small entries)
         for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
-          const int i = e & (BJ_W - 1), j = e >> 6;
-          Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = Sb[(size_t)Pp * BJ_W * BJ_W + j * BJ_W + i];
+          const int i = e & (BJ_W - 1), j = e >> 6, gi = bj_gidx(IJp, i), gj = bj_gidx(IJq, j);
+          const real v = Sb[(size_t)Pp * BJ_W * BJ_W + j * BJ_W + i];
+          Anew[(size_t)gj * ld + gi] = v;
+          seen(gi, gj, v);
         }
       } else {
         for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
-          const int i = e & (BJ_W - 1), j = e >> 6;
-          const size_t g = (size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i);
-          Anew[g] = Aold[g];
+          const int i = e & (BJ_W - 1), j = e >> 6, gi = bj_gidx(IJp, i), gj = bj_gidx(IJq, j);
+          const size_t g = (size_t)gj * ld + gi;
+          const real v = Aold[g];
+          Anew[g] = v;
+          seen(gi, gj, v);
         }
       }
-      return;
-    }
-    if (!fP && !fQ) { // neither pair rotated: the tile and its mirror move to the other copy as they are
+    } else if (!fP && !fQ) { // neither pair rotated: the tile and its mirror move to the other copy as they are
       for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
-        const int i = e & (BJ_W - 1), j = e >> 6;
-        const size_t g = (size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i), gm = (size_t)bj_gidx(IJp, j) * ld + bj_gidx(IJq, i);
-        Anew[g] = Aold[g];
-        Anew[gm] = Aold[gm];
+        const int i = e & (BJ_W - 1), j = e >> 6, gi = bj_gidx(IJp, i), gj = bj_gidx(IJq, j);
+        const size_t g = (size_t)gj * ld + gi, gm = (size_t)bj_gidx(IJp, j) * ld + bj_gidx(IJq, i);
+        const real v = Aold[g], vm = Aold[gm];
+        Anew[g] = v;
+        Anew[gm] = vm;
+        seen(gi, gj, v);
+        seen(bj_gidx(IJq, i), bj_gidx(IJp, j), vm);
       }
-      return;
-    }
-    // X[i][k] = A[P_i, Q_k]; Q_Q[k][j] and Q_P[k][i], identity where the pair did not rotate
+    } else {
+      // X[i][k] = A[P_i, Q_k]; Q_Q[k][j] and Q_P[k][i], identity where the pair did not rotate
 #pragma unroll 4
-    for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
-      const int i = e & (BJ_W - 1), kk = e >> 6;
-      xs[i * BJ_LD + kk] = Aold[(size_t)bj_gidx(IJq, kk) * ld + bj_gidx(IJp, i)];
-      // Qbuf is column-major: Q[k][j] at j * 64 + k -> qq[j * BJ_LD + k]: here (kk, i) play (j, k)
-      qq[kk * BJ_LD + i] = fQ ? Qb[(size_t)Qp * BJ_W * BJ_W + kk * BJ_W + i] : (i == kk ? (real)1 : (real)0);
-      qp[kk * BJ_LD + i] = fP ? Qb[(size_t)Pp * BJ_W * BJ_W + kk * BJ_W + i] : (i == kk ? (real)1 : (real)0);
+      for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
+        const int i = e & (BJ_W - 1), kk = e >> 6;
+        xs[i * BJ_LD + kk] = Aold[(size_t)bj_gidx(IJq, kk) * ld + bj_gidx(IJp, i)];
+        // Qbuf is column-major: Q[k][j] at j * 64 + k -> qq[j * BJ_LD + k]: here (kk, i) play (j, k)
+        qq[kk * BJ_LD + i] = fQ ? Qb[(size_t)Qp * BJ_W * BJ_W + kk * BJ_W + i] : (i == kk ? (real)1 : (real)0);
+        qp[kk * BJ_LD + i] = fP ? Qb[(size_t)Pp * BJ_W * BJ_W + kk * BJ_W + i] : (i == kk ? (real)1 : (real)0);
+      }
+      __syncthreads();
+      bj_gemm64(xs, qq, ts, tid); // T = X Q_Q, T[i][j] at ts[j * BJ_LD + i]
+      __syncthreads();
+      bj_gemm64(qp, ts, xs, tid); // O = Q_P' T: L[i][k] = Q_P[k][i] = qp[i * BJ_LD + k], R[k][j] = T[k][j] = ts[j * BJ_LD + k]
+      __syncthreads();
+      for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
+        const int i = e & (BJ_W - 1), j = e >> 6, gi = bj_gidx(IJp, i), gj = bj_gidx(IJq, j);
+        const real v = xs[j * BJ_LD + i];
+        Anew[(size_t)gj * ld + gi] = v;                                                   // A'[P_i, Q_j]
+        Anew[(size_t)bj_gidx(IJp, j) * ld + bj_gidx(IJq, i)] = xs[i * BJ_LD + j];         // A'[Q_i, P_j] = A'[P_j, Q_i]
+        seen(gi, gj, v);
+      }
     }
-    __syncthreads();
-    bj_gemm64(xs, qq, ts, tid); // T = X Q_Q, T[i][j] at ts[j * BJ_LD + i]
-    __syncthreads();
-    bj_gemm64(qp, ts, xs, tid); // O = Q_P' T: L[i][k] = Q_P[k][i] = qp[i * BJ_LD + k], R[k][j] = T[k][j] = ts[j * BJ_LD + k]
-    __syncthreads();
-    for (int e = tid; e < BJ_W * BJ_W; e += BJ_UPD_THREADS) {
-      const int i = e & (BJ_W - 1), j = e >> 6;
-      Anew[(size_t)bj_gidx(IJq, j) * ld + bj_gidx(IJp, i)] = xs[j * BJ_LD + i];                   // A'[P_i, Q_j]
-      Anew[(size_t)bj_gidx(IJp, j) * ld + bj_gidx(IJq, i)] = xs[i * BJ_LD + j];                   // A'[Q_i, P_j] = A'[P_j, Q_i]
+    if (left_bits) { // (uniform)
+      left = block_max(left, red_left);
+      if (tid == 0 && left > bp_from_bits(*left_bits)) atomicMax(left_bits, bp_bits(left)); // (a stale read is too small: a needless atomic, never a missing one)
     }
     return;
   }
@@ -857,6 +877,7 @@ struct BjFusedArgs {
   int next_sweep;  // inner sweep belongs to the sweep after the current one (inn_step == 0 of it)
   int qin, qout;   // which of the two Q / S' / flag buffers the update reads / the inner sweep writes
   int cross;
+  int scan;        // the last update of a block's sweep records the largest off-diagonal entry it writes (no k_bp_offscan launch)
   int flat;        // inner sweep's prologue with ONE level of global loads (0: rounds 4-5's three levels; A/B measurements)
   int one_d;       // one-dimensional grid, inner-sweep workgroups of all blocks first (0: x = job, y = block; A/B measurements)
 };
@@ -894,7 +915,8 @@ __global__ __launch_bounds__(BJ_UPD_THREADS) void k_bj_fused(BigPsdView B, real 
     if (!F.do_update) return;
     if (bx == npmax && tid == 0) ctl->cur[F.slot ^ 1] = upd_active ? cur ^ 1 : cur;
     if (!upd_active) return;
-    bj_update_job(B, bj_smem, Qin, Sin, Fin, npmax, b, bx - npmax, F.upd_step, F.cross, sh, Aold, (cur ? B.A : B.A1) + mat, B.V + mat);
+    bj_update_job(B, bj_smem, Qin, Sin, Fin, npmax, b, bx - npmax, F.upd_step, F.cross, sh, Aold, (cur ? B.A : B.A1) + mat, B.V + mat,
+                  F.scan && F.upd_step == ost - 1 ? &ctl->left_bits : nullptr); // the last update of THIS block's sweep looks at what it leaves
     return;
   }
   // ---- inner sweep of step inn_step on the matrix as the update of this launch leaves it
@@ -1362,6 +1384,7 @@ struct BigPsd {
                              // are enqueued before the first read-back (a cold projection's ~10 must not size the next warm one's batch)
   bool fused = true;         // blocked: one launch per outer step (k_bj_fused) instead of k_bj_inner + k_bj_update
   DevBuf<real> normpart;     // k_bp_norm_part's partial sums
+  bool offscan_fold = true;  // the scan inside the last update of a sweep (fused step) instead of k_bp_offscan's launch
   bool flat_prologue = true; // k_bj_fused: the inner sweep's subproblem from one level of global loads
   bool grid_1d = true;       // k_bj_fused: one-dimensional grid, inner-sweep workgroups of all blocks first
   bool offscan = true;       // a pass over the matrix after every sweep decides whether another sweep would rotate anything (k_bp_offscan)
@@ -1387,6 +1410,8 @@ struct BigPsd {
     if (const char *e = opt_get("psd_blocked")) blocked = atoi(e) != 0; // 0: the single-column steps of round 2 (A/B measurements)
     ld = blocked ? (kmax + BJ_W - 1) / BJ_W * BJ_W : (kmax + 1) & ~1;
     normpart.alloc((size_t)nbig * BP_NORM_G);
+    offscan_fold = true;
+    if (const char *e = opt_get("psd_offscan")) offscan_fold = atoi(e) != 2; // 2: the scan as a launch of its own (A/B measurements)
     flat_prologue = true;
     if (const char *e = opt_get("psd_prologue")) flat_prologue = atoi(e) != 0; // 0: rounds 4-5's three dependent levels of loads (A/B measurements)
     grid_1d = true;
@@ -1456,6 +1481,7 @@ struct BigPsd {
     // read-back, then one at a time (consecutive ADMM iterates need nearly the same count; a block that has converged makes every
     // later launch return at once, as in the PCG loop; the sweep cap of cones.c:1031 is enforced on the device).  One host
     // round trip per sweep cost 50 - 100 us -- a third of a projection of 32 blocks of order 100.
+    const bool scan_in_update = offscan && blocked && fused && offscan_fold; // the fused step's last update of a sweep does the scan
     const int g_scan = std::max(1, std::min(ld / 2, std::max(ld / 8, 1024 / nbig))); // whole columns per workgroup; ~1024 workgroups in all (order 1024 on 64: 21 us)
     int enq = 0, batch = std::max(1, std::min(sweeps_hint[warm ? 1 : 0] - 1, warm ? 8 : 12)); // (all of them: measured the same, 2.70 vs 2.71 ms at 256 x 8)
     while (h_rem[0] > 0 && enq < PSD_MAX_SWEEPS + 4) {
@@ -1466,13 +1492,13 @@ struct BigPsd {
           const int g_fused = npmax + g_upd;
           for (int step = 0; step < osteps; ++step, ++gstep) {
             if (first_launch) { // inner sweep of step 0 of the first sweep; nothing to update yet
-              const BjFusedArgs F0{(int)(gstep & 1), 0, 0, 0, 0, 0, (int)(qgen & 1), cross ? 1 : 0, flat_prologue ? 1 : 0, grid_1d ? 1 : 0};
+              const BjFusedArgs F0{(int)(gstep & 1), 0, 0, 0, 0, 0, (int)(qgen & 1), cross ? 1 : 0, scan_in_update ? 1 : 0, flat_prologue ? 1 : 0, grid_1d ? 1 : 0};
               hipLaunchKernelGGL(k_bj_fused, grid_1d ? dim3(npmax * nbig) : dim3(npmax, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F0);
               ++qgen;
               first_launch = false;
             }
             const bool last = step + 1 == osteps;
-            const BjFusedArgs F{(int)(gstep & 1), 1, step, last ? 0 : step + 1, last ? 1 : 0, (int)((qgen - 1) & 1), (int)(qgen & 1), cross ? 1 : 0, flat_prologue ? 1 : 0, grid_1d ? 1 : 0};
+            const BjFusedArgs F{(int)(gstep & 1), 1, step, last ? 0 : step + 1, last ? 1 : 0, (int)((qgen - 1) & 1), (int)(qgen & 1), cross ? 1 : 0, scan_in_update ? 1 : 0, flat_prologue ? 1 : 0, grid_1d ? 1 : 0};
             hipLaunchKernelGGL(k_bj_fused, grid_1d ? dim3(g_fused * nbig) : dim3(g_fused, nbig), dim3(BJ_UPD_THREADS), BJ_UPDATE_LDS, st, B, Qbuf.p, Sbuf.p, Qflag.p, npmax, F);
             ++qgen;
           }
@@ -1488,7 +1514,7 @@ struct BigPsd {
         for (int step = 0; step < ld - 1; ++step, ++gstep)
           hipLaunchKernelGGL(k_bp_step, dim3(g_step, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1) | (step << 1));
       }
-      if (offscan) hipLaunchKernelGGL(k_bp_offscan, dim3(g_scan, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1));
+      if (offscan && !scan_in_update) hipLaunchKernelGGL(k_bp_offscan, dim3(g_scan, nbig), dim3(BP_THREADS), 0, st, B, (int)(gstep & 1));
       hipLaunchKernelGGL(k_bp_sweep_end, dim3(1), dim3(SCSAMD_WAVE), 0, st, B, status, remaining.p, offscan ? 1 : 0);
      }
       HIP_CHECK(hipMemcpyAsync(h_rem, remaining.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));

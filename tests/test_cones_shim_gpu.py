@@ -332,7 +332,7 @@ def test_measurement_forms_of_the_large_block_iteration_still_project(env, monke
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), (env, np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("env", [dict(SCS_AMD_PSD_OFFSCAN="0"), dict(SCS_AMD_PSD_GRID="0"), dict(SCS_AMD_PSD_PROLOGUE="0"),
+@pytest.mark.parametrize("env", [dict(SCS_AMD_PSD_OFFSCAN="0"), dict(SCS_AMD_PSD_OFFSCAN="2"), dict(SCS_AMD_PSD_GRID="0"), dict(SCS_AMD_PSD_PROLOGUE="0"),
                                  dict(SCS_AMD_PSD_OFFSCAN="0", SCS_AMD_PSD_GRID="0", SCS_AMD_PSD_PROLOGUE="0")])
 def test_round_6_forms_of_the_large_block_iteration_change_no_bit(env, monkeypatch):
     """Round 6 (profiles/r6_psd_big.md): the pass over the matrix that replaces the closing sweep (a sweep that rotates nothing changes
