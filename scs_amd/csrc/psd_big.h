@@ -1110,6 +1110,8 @@ __global__ __launch_bounds__(SCSAMD_WAVE) void k_bp_sweep_end(BigPsdView B, int 
 // launches of ~20 us there, 8 at order 256: 5 % of a cold projection, a third to a half of a warm-started one of 2 - 3 sweeps).
 // Same rule (|a_pq| > thr rotates, both indices below k), same final matrix bit for bit; both triangles are read, so whichever mirror
 // entry a rotation would have looked at is covered.  slot: parity of the next launch (ctl.cur), as k_bp_scale.
+// The fused step does this inside the last update of the sweep (bj_update_job's left_bits: that launch rewrites the whole matrix anyway);
+// this kernel serves the forms that do not come through there (two-launch step, single-column steps, option psd_offscan = 2).
 // (Closing the sweep from the workgroup that finishes last -- a ticket behind a fence -- instead of k_bp_sweep_end's launch was
 // measured and dropped: an agent-scope fence per workgroup writes the XCD's L2 back; 100 x 32: 1.73 vs 1.35 ms per projection.)
 __global__ __launch_bounds__(BP_THREADS) void k_bp_offscan(BigPsdView B, int slot) {
