@@ -484,3 +484,28 @@ def test_pipelined_psd_kernel_fp32_orders_64_and_72():
         assert err <= 2e-4, (rep, err)
         assert np.abs(x - v).max() > 1e-2
     lib.scs_amd_cone_finish(w)
+
+
+def test_blocked_psd_iteration_fp32_orders_beyond_the_lds_path():
+    """The -DSFLOAT build of the blocked iteration (psd_big.h: plain-loop products, the same scan / norm / prologue / grid as the fp64
+    build): orders 100, 130 and 97 in one cone against the float64 numpy projection at fp32 accuracy, cold and over a warm-started
+    sequence."""
+    from scs_amd import problems
+    lib = capi.load("libscsamd_f32.so")
+    T32 = capi.T32
+    cone = dict(s=[100, 130, 97])
+    m = capi.cone_rows(cone)
+    k = capi.make_cone(cone, T32)
+    w = lib.scs_amd_cone_init(C.byref(k), m, None)
+    assert w
+    rng = np.random.default_rng(23)
+    v = rng.standard_normal(m)
+    for rep in range(5):
+        v = v + (0.3 if rep < 2 else 1e-3) * rng.standard_normal(m)
+        x = v.astype(np.float32)
+        want = problems.proj_dual_cone_np(x.astype(np.float64), cone)
+        assert lib.scs_amd_cone_proj_dual(w, x.ctypes.data_as(T32.fp), None) == 0
+        err = np.abs(x - want).max() / max(1.0, np.abs(want).max())
+        assert err <= 5e-4, (rep, err)
+        assert np.abs(x - v).max() > 1e-2
+    lib.scs_amd_cone_finish(w)
