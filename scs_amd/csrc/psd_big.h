@@ -816,7 +816,8 @@ __device__ __forceinline__ void bj_update_job(const BigPsdView &B, unsigned char
     }
     if (left_bits) { // (uniform)
       left = block_max(left, red_left);
-      if (tid == 0 && left > bp_from_bits(*left_bits)) atomicMax(left_bits, bp_bits(left)); // (a stale read is too small: a needless atomic, never a missing one)
+      // (the relaxed read may be behind the other workgroups' maxima, i.e. too small: a needless atomic then, never a missing one)
+      if (tid == 0 && left > bp_from_bits(__hip_atomic_load(left_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMax(left_bits, bp_bits(left));
     }
     return;
   }
@@ -1130,8 +1131,8 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_offscan(BigPsdView B, int slo
     }
   }
   mx = block_max(mx, red);
-  // (the plain read may be stale, i.e. too small: then the atomic is issued needlessly, never skipped wrongly)
-  if (threadIdx.x == 0 && mx > bp_from_bits(c->left_bits)) atomicMax(&c->left_bits, bp_bits(mx));
+  // (the relaxed read may be behind the other workgroups' maxima, i.e. too small: a needless atomic then, never a missing one)
+  if (threadIdx.x == 0 && mx > bp_from_bits(__hip_atomic_load(&c->left_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMax(&c->left_bits, bp_bits(mx));
 }
 
 // W = V diag(sqrt(max(lambda, 0)))   (cones.c:1036-1044), in place
