@@ -1380,6 +1380,7 @@ struct BigPsd {
   long long calls = 0;
   DevBuf<BigPsdCtl> ctl;
   DevBuf<int> remaining;
+  PinnedBuf<int> hrem;       // host copy of `remaining`
   long long sweeps_total = 0, projections = 0;
   bool warm_ok = true;
   bool blocked = true;       // tournament over 32-wide block columns with MFMA updates (k_bj_*); false: single columns (k_bp_step)
@@ -1445,6 +1446,7 @@ struct BigPsd {
     calls = 0;
     ctl.alloc(nbig);
     remaining.alloc(2);
+    hrem.alloc(2);
     HIP_CHECK(hipStreamSynchronize(st));
   }
 
@@ -1473,7 +1475,9 @@ struct BigPsd {
     }
     hipLaunchKernelGGL(k_bp_norm_part, dim3(BP_NORM_G, nbig), dim3(BP_THREADS), 0, st, B, normpart.p);
     hipLaunchKernelGGL(k_bp_norm, dim3(nbig), dim3(SCSAMD_WAVE), 0, st, B, (const real *)normpart.p);
-    int h_rem[2] = {nbig, 0};
+    int *h_rem = hrem.p; // (pinned: the read-back of two ints into pageable memory went through the runtime's staging copy)
+    h_rem[0] = nbig;
+    h_rem[1] = 0;
     long long qgen = 0;  // fused step: generations of Q / S' / flags written so far
     bool first_launch = true;
     long long gstep = 0; // launches so far: the copy of A a block is in alternates with the steps IT took (ctl.cur)
