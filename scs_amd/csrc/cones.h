@@ -45,6 +45,7 @@ struct ConeDev {
   int ep = 0, ed = 0, psize = 0, exp_off = 0;
   DevBuf<real> pow_a;       // psize power-cone parameters (negative = dual cone)
   DevBuf<int> status;       // [0] = PSD block projections that hit the Jacobi sweep cap since the last take_status()
+  PinnedBuf<int> hstatus;   // its host copy (pinned: take_status runs at every residual evaluation)
   int take_status(hipStream_t st);
 
   // host staging for the B1' boundary

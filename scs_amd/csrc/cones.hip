@@ -1105,6 +1105,7 @@ void ConeDev::init(const ScsCone *k, int m_, const real *D, hipStream_t s) {
   pow_a.alloc(psize > 0 ? psize : 1);
   if (psize > 0) pow_a.upload(k->p, psize, stream);
   status.alloc(1);
+  hstatus.alloc(1);
   HIP_CHECK(hipStreamSynchronize(stream));
   if (off != m) throw HipError("scs_amd: cone rows do not add up to m");
 }
@@ -1163,9 +1164,9 @@ void ConeDev::proj_primal(real *cw, const real *r_y) {
 
 // number of PSD block projections that hit the sweep cap since the last call; resets the device counter
 int ConeDev::take_status(hipStream_t st) {
-  int h = 0;
-  HIP_CHECK(hipMemcpyAsync(&h, status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(hstatus.p, status.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  const int h = hstatus.p[0];
   if (h) HIP_CHECK(hipMemsetAsync(status.p, 0, sizeof(int), st));
   return h;
 }
