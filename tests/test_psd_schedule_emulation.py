@@ -99,7 +99,7 @@ def _inner(S, g, k, thr, kind):
     return Q, S, rotated, offmax
 
 
-def _project(Ain, k, cross):
+def _project(Ain, k, cross, scan=False):
     K64 = (k + W - 1) // W * W
     nbc, npairs = K64 // B, K64 // W
     A = [np.zeros((K64, K64)), np.zeros((K64, K64))]
@@ -130,6 +130,10 @@ def _project(Ain, k, cross):
             cur ^= 1
         if off <= thr:
             return A[cur], V, sweep
+        if scan:  # round 6 (psd_big.h, k_bp_offscan / the last update's left_bits): would the NEXT sweep rotate anything?
+            left = np.abs(A[cur][:k, :k] - np.diag(np.diag(A[cur][:k, :k]))).max()
+            if left <= thr:
+                return A[cur], V, sweep
     return A[cur], V, 31
 
 
@@ -280,3 +284,18 @@ def test_incremental_round_robin_positions_equal_the_closed_form(K2):
                 a = 1 if a == K2 - 1 else a + 1
             b = 1 if b == K2 - 1 else b + 1
     assert len(met) == K2 * (K2 - 1) // 2
+
+
+@pytest.mark.parametrize("k,cross", [(100, True), (70, False)])
+def test_closing_by_a_scan_ends_one_sweep_earlier_with_the_same_matrix(k, cross):
+    """Round 6: the iteration used to end with a sweep that meets no entry above the threshold, i.e. one that rotates nothing.  Reading
+    the largest off-diagonal entry off the matrix after every sweep (psd_big.h: k_bp_offscan, or the last update of the sweep itself)
+    ends it exactly one sweep earlier and leaves A and V bit for bit as the closing sweep would have (that sweep changes nothing)."""
+    rng = np.random.default_rng(7 * k)
+    M = rng.standard_normal((k, k))
+    Ain = (M + M.T) / 2
+    D0, V0, s0 = _project(Ain, k, cross)
+    D1, V1, s1 = _project(Ain, k, cross, scan=True)
+    assert s1 == s0 - 1
+    assert np.array_equal(D0, D1) and np.array_equal(V0, V1)
+
