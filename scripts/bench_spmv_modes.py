@@ -21,7 +21,7 @@ MODES = {
     "ls8": {"SCS_AMD_WR_LOCKSTEP": "1", "SCS_AMD_WR_LS_WPB": "8", "SCS_AMD_WR_LS_BARRIERS": "4"},
 }
 TOKENS = {"wpc": "SCS_AMD_WR_WPC", "nnz": "SCS_AMD_WR_NNZ", "pipe": "SCS_AMD_WR_PIPE", "ls": "SCS_AMD_WR_LOCKSTEP", "wave": "SCS_AMD_WAVEROWS",
-          "bars": "SCS_AMD_WR_LS_BARRIERS", "wpb": "SCS_AMD_WR_LS_WPB", "ro": "SCS_AMD_REORDER", "rh": "SCS_AMD_REORDER_HOME", "rs": "SCS_AMD_REORDER_STRIDE", "rb": "SCS_AMD_REORDER_BLOCK", "cgthree": "SCS_AMD_CG3", "graph": "SCS_AMD_GRAPH"}
+          "bars": "SCS_AMD_WR_LS_BARRIERS", "wpb": "SCS_AMD_WR_LS_WPB", "ro": "SCS_AMD_REORDER", "rh": "SCS_AMD_REORDER_HOME", "rs": "SCS_AMD_REORDER_STRIDE", "rb": "SCS_AMD_REORDER_BLOCK", "cgthree": "SCS_AMD_CG3", "graph": "SCS_AMD_GRAPH", "lso": "SCS_AMD_WR_LS_ORDER", "nt": "SCS_AMD_VEC_NT", "dir": "SCS_AMD_DIR_MODE"}
 
 
 def mode_env(mode):
